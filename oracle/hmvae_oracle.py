@@ -1,0 +1,495 @@
+"""CPU oracle for the hm-vae training hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (fp32, CPU) restatement of the reference algorithm for the path
+named in BASELINE.json: skeleton topology, skeleton-aware conv / pool / unpool,
+rot-6D lift, forward kinematics, the TwoHierSAVAE encoder/decoder, losses and one Adam step.
+Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import it;
+the product package (`hm_vae_amd/`) never does and fails loudly without its HIP library.
+
+Parity pin: every function below is checked in `tests/test_oracle_golden.py` against fixtures in
+`tests/golden/` that were produced by running the UNMODIFIED reference on CPU in the build
+container (`tools/gen_golden.py`), plus the reference's own known-answer data
+(`rest_pose_coord.npy`, the topology dump in `skeleton.py:464-477`).
+
+Each function cites the reference lines it follows (paths relative to the reference root).
+Third-party arithmetic (conv1d, reflect pad, linear interpolation, Adam) is PyTorch's, exactly as
+in the reference (SURVEY.md §8c last row).
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SMPL24_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]
+
+
+# --------------------------------------------------------------------------------------
+# topology (skeleton.py:306-315, 364-410, 159-231)
+# --------------------------------------------------------------------------------------
+def skeleton_edges(parents):
+    """skeleton.py:306-315 — virtual root edge (0, n_joints) first, then (parent, child)."""
+    n = len(parents)
+    return [(0, n)] + [(parents[j], j) for j in range(1, n)]
+
+
+def edge_distances(edges):
+    """skeleton.py:364-387 — edges are adjacent when they share a joint id; all-pairs hops."""
+    m = len(edges)
+    big = 100000
+    d = np.full((m, m), big, dtype=np.int64)
+    for a in range(m):
+        for b in range(m):
+            if a == b:
+                d[a, b] = 0
+            elif set(edges[a]) & set(edges[b]):
+                d[a, b] = 1
+    for k in range(m):
+        d = np.minimum(d, d[:, k:k + 1] + d[k:k + 1, :])
+    return d
+
+
+def edge_neighbours(edges, dist):
+    """skeleton.py:390-410 — per edge, sorted ids of edges within `dist` hops."""
+    d = edge_distances(edges)
+    return [[int(j) for j in np.nonzero(d[i] <= dist)[0]] for i in range(len(edges))]
+
+
+def pool_plan(edges, last_pool=False):
+    """skeleton.py:173-207 — chains from joint 0, merged pairwise (odd head kept alone).
+
+    Returns (seq_list, pooling_list, new_edges).
+    """
+    degree = {}
+    for a, b in edges:
+        degree[a] = degree.get(a, 0) + 1
+        degree[b] = degree.get(b, 0) + 1
+    chains = []
+
+    def walk(joint, chain):
+        if degree[joint] > 2 and joint != 0:
+            chains.append(chain)
+            chain = []
+        if degree[joint] == 1:
+            chains.append(chain)
+            return
+        for idx, e in enumerate(edges):
+            if e[0] == joint:
+                walk(e[1], chain + [idx])
+
+    walk(0, [])
+    pooling, coarse = [], []
+    for chain in chains:
+        if last_pool:
+            pooling.append(list(chain))
+            continue
+        rest = list(chain)
+        if len(rest) % 2 == 1:
+            pooling.append([rest[0]])
+            coarse.append(edges[rest[0]])
+            rest = rest[1:]
+        for i in range(0, len(rest), 2):
+            pooling.append([rest[i], rest[i + 1]])
+            coarse.append([edges[rest[i]][0], edges[rest[i + 1]][1]])
+    return chains, pooling, coarse
+
+
+def pool_matrix(pooling, n_in_edges, ch):
+    """skeleton.py:219-224 — mean over the merged edges, channel-wise."""
+    w = torch.zeros(len(pooling) * ch, n_in_edges * ch)
+    for i, grp in enumerate(pooling):
+        for j in grp:
+            for c in range(ch):
+                w[i * ch + c, j * ch + c] = 1.0 / len(grp)
+    return w
+
+
+def unpool_matrix(pooling, ch):
+    """skeleton.py:248-253 — every fine edge copies its coarse edge."""
+    n_out = sum(len(g) for g in pooling)
+    w = torch.zeros(n_out * ch, len(pooling) * ch)
+    for i, grp in enumerate(pooling):
+        for j in grp:
+            for c in range(ch):
+                w[j * ch + c, i * ch + c] = 1.0
+    return w
+
+
+def conv_mask(neigh, cin, cout, ksize):
+    """skeleton.py:34-39, 58-60 — 1 where the input channel belongs to a neighbour edge."""
+    n = len(neigh)
+    ci, co = cin // n, cout // n
+    m = torch.zeros(cout, cin, ksize)
+    for i, nb in enumerate(neigh):
+        cols = [k * ci + c for k in nb for c in range(ci)]
+        m[co * i:co * (i + 1), cols, :] = 1
+    return m
+
+
+# --------------------------------------------------------------------------------------
+# rotation lift + forward kinematics (my_tools.py:6-39, fk_layer.py:47-93)
+# --------------------------------------------------------------------------------------
+def _unit(v):
+    """my_tools.py:6-8 — v / max(||v||_2, 1e-6)."""
+    return v / v.norm(dim=-1, keepdim=True).clamp_min(1e-6)
+
+
+def _cross(u, v):
+    """my_tools.py:10-17 — component formula with separately rounded products (no fma), which is
+    what decides the result for (near-)parallel inputs."""
+    return torch.stack((u[..., 1] * v[..., 2] - u[..., 2] * v[..., 1],
+                        u[..., 2] * v[..., 0] - u[..., 0] * v[..., 2],
+                        u[..., 0] * v[..., 1] - u[..., 1] * v[..., 0]), dim=-1)
+
+
+def rot6d_to_matrix(p):
+    """my_tools.py:19-39 — x=n(a), z=n(x×b), y=z×x; columns of R are x,y,z."""
+    a, b = p[..., 0:3], p[..., 3:6]
+    x = _unit(a)
+    z = _unit(_cross(x, b))
+    y = _cross(z, x)
+    return torch.stack((x, y, z), dim=-1)
+
+
+def matrix_to_rot6d(r):
+    """seq_two_hier_sa_vae.py:773-779 — first two columns, [col0 ‖ col1]."""
+    return torch.cat((r[..., :, 0], r[..., :, 1]), dim=-1)
+
+
+def fk_positions(rot, parents, offsets):
+    """fk_layer.py:63-93 — p_0 = off_0, G_0 = R_0; G_i = G_par·R_i, p_i = G_par·off_i + p_par.
+
+    rot: (N,J,3,3) or (N,J,6); offsets: (J,3) tensor.  Returns (N,J,3).
+    """
+    if rot.shape[-1] == 6:
+        rot = rot6d_to_matrix(rot)
+    n, j = rot.shape[0], rot.shape[1]
+    off = offsets.to(rot.dtype)
+    glob = [None] * j
+    pos = [None] * j
+    glob[0] = rot[:, 0]
+    pos[0] = off[0].expand(n, 3)
+    for i in range(1, j):
+        pa = parents[i]
+        glob[i] = glob[pa] @ rot[:, i]
+        pos[i] = (glob[pa] @ off[i]) + pos[pa]
+    return torch.stack(pos, dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# layers (skeleton.py:95-105, 228-231, 258-261)
+# --------------------------------------------------------------------------------------
+def skel_conv(x, weight, mask, bias, stride, pad, pad_mode="reflect"):
+    """skeleton.py:95-105."""
+    xp = F.pad(x, (pad, pad), mode=pad_mode) if pad > 0 else x
+    return F.conv1d(xp, weight * mask, bias, stride)
+
+
+def _pad_mode(name):
+    return {"zeros": "constant", "reflection": "reflect"}.get(name, name)
+
+
+def level_strides(T, L):
+    """seq_two_hier_sa_vae.py:79-90, 107-118 — per-level conv stride (and timestep ladder)."""
+    s = []
+    for i in range(L):
+        if T == 8:
+            s.append(1 if (i == 0 or i == L - 1) else 2)
+        elif T == 16:
+            s.append(1 if i == 0 else 2)
+        else:
+            s.append(2)
+    ts = [T]
+    for st in s:
+        ts.append(ts[-1] // st)
+    return s, ts
+
+
+class Plan:
+    """Static structure of the TwoHierSAVAE for one config (seq_two_hier_sa_vae.py:53-258)."""
+
+    def __init__(self, hp, parents=SMPL24_PARENTS):
+        L = hp["num_layers"]
+        T = hp["train_seq_len"]
+        self.hp, self.L, self.T = hp, L, T
+        self.K = hp["kernel_size"]
+        self.pad = (self.K - 1) // 2
+        self.pad_mode = _pad_mode(hp["padding_mode"])
+        self.strides, self.tsteps = level_strides(T, L)
+        self.ch_base = [6 * (2 ** i) for i in range(L + 1)]
+        self.topo = [skeleton_edges(parents)]
+        self.neigh, self.pooling, self.edge_num = [], [], [len(self.topo[0])]
+        self.enc_cin, self.enc_cout = [], []
+        for i in range(L):
+            nb = edge_neighbours(self.topo[i], hp["skeleton_dist"])
+            self.neigh.append(nb)
+            self.enc_cin.append(self.ch_base[i] * self.edge_num[i])
+            self.enc_cout.append(self.ch_base[i + 1] * self.edge_num[i])
+            _, pl, ne = pool_plan(self.topo[i], last_pool=(i == L - 1))
+            self.pooling.append(pl)
+            self.topo.append(ne)
+            self.edge_num.append(len(ne) if i < L - 1 else len(pl))
+        # NB: on the last level new_edges is empty (last_pool) — edge_num follows len(pooling).
+        self.edge_num[L] = len(self.pooling[L - 1])
+        self.channel_list = [self.enc_cin[0]] + self.enc_cout
+        self.dec_ts = list(reversed(self.tsteps))
+        self.dec_cin, self.dec_cout, self.dec_bias, self.dec_up = [], [], [], []
+        for i in range(L):
+            cin = self.channel_list[L - i] * (2 if i == L - 1 else 1)
+            self.dec_cin.append(cin)
+            self.dec_cout.append(cin // 4 if i == L - 1 else cin // 2)
+            self.dec_bias.append(i == 0 or i == L - 1)
+            if T == 8:
+                up = (i != L - 1 and i != 0)
+            elif T == 16:
+                up = (i != L - 1)
+            else:
+                up = True
+            self.dec_up.append(up)
+        d, sd = hp["latent_d"], hp["shallow_latent_d"]
+        self.lat_dim = [sd] + [d] * (L - 1)            # encoder level i -> latent width
+
+    def dec_conv_key(self, i):
+        """Sequential index of the conv inside dec.layers[i]: [Upsample?] + Unpool + Conv (:233-251)."""
+        return "dec.layers.%d.%d" % (i, 2 if self.dec_up[i] else 1)
+
+    def dec_unpool_key(self, i):
+        return "dec.layers.%d.%d" % (i, 1 if self.dec_up[i] else 0)
+
+
+def reference_param_shapes(plan):
+    """Names/shapes of the reference state_dict tensors that carry values (no aliases, no constants)."""
+    L, K = plan.L, plan.K
+    out = {}
+    for i in range(L):
+        out["enc.layers.%d.0.weight" % i] = (plan.enc_cout[i], plan.enc_cin[i], K)
+        out["enc.layers.%d.0.bias" % i] = (plan.enc_cout[i],)
+        feat = plan.ch_base[i + 1] * plan.tsteps[i + 1]
+        out["enc.latent_enc_layers.%d.weight" % i] = (2 * plan.lat_dim[i], feat)
+        out["enc.latent_enc_layers.%d.bias" % i] = (2 * plan.lat_dim[i],)
+    for i in range(L):
+        out[plan.dec_conv_key(i) + ".weight"] = (plan.dec_cout[i], plan.dec_cin[i], K)
+        if plan.dec_bias[i]:
+            out[plan.dec_conv_key(i) + ".bias"] = (plan.dec_cout[i],)
+        lat = plan.lat_dim[L - 1 - i]
+        feat = plan.ch_base[L - i] * plan.dec_ts[i]
+        out["dec.latent_dec_layers.%d.weight" % i] = (feat, lat)
+        out["dec.latent_dec_layers.%d.bias" % i] = (feat,)
+    return out
+
+
+def name_seeded_params(plan):
+    """Deterministic weights keyed by reference state_dict name (fixtures are too big to commit).
+
+    value = N(0,1) from numpy default_rng(crc32(name)), scaled ~kaiming; conv weights are multiplied
+    by the neighbour mask exactly like a trained reference checkpoint (masked entries stay 0).
+    """
+    params = {}
+    masks = oracle_masks(plan)
+    for name, shape in reference_param_shapes(plan).items():
+        rng = np.random.default_rng(zlib.crc32(name.encode()))
+        v = rng.standard_normal(shape).astype(np.float32)
+        if name.endswith("bias"):
+            v *= 0.05
+        elif len(shape) == 3:
+            m = masks[name.replace("weight", "mask")].numpy()
+            fan = m[:, :, 0].sum(axis=1, keepdims=True)[:, :, None] * shape[2]
+            v = v * m * np.sqrt(2.0 / np.maximum(fan, 1.0)).astype(np.float32)
+        else:
+            v *= np.float32(math.sqrt(2.0 / shape[1]))
+        params[name] = torch.from_numpy(np.ascontiguousarray(v.astype(np.float32)))
+    return params
+
+
+def oracle_masks(plan):
+    L, K = plan.L, plan.K
+    out = {}
+    for i in range(L):
+        out["enc.layers.%d.0.mask" % i] = conv_mask(plan.neigh[i], plan.enc_cin[i], plan.enc_cout[i], K)
+        out[plan.dec_conv_key(i) + ".mask"] = conv_mask(plan.neigh[L - 1 - i], plan.dec_cin[i], plan.dec_cout[i], K)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# model
+# --------------------------------------------------------------------------------------
+class OracleVAE:
+    """Functional restatement of TwoHierSAVAEModel (seq_two_hier_sa_vae.py:296-474).
+
+    `params` maps reference state_dict names to leaf tensors (requires_grad as needed).
+    """
+
+    def __init__(self, hp, params=None, parents=SMPL24_PARENTS, offsets=None):
+        self.hp = hp
+        self.plan = Plan(hp, parents)
+        self.parents = list(parents)
+        if offsets is None:
+            raise ValueError("offsets (J,3) required")
+        self.offsets = torch.as_tensor(offsets, dtype=torch.float32)
+        self.masks = oracle_masks(self.plan)
+        p = self.plan
+        self.pool_w = [pool_matrix(p.pooling[i], p.edge_num[i], p.enc_cout[i] // p.edge_num[i]) for i in range(p.L)]
+        self.unpool_w = [unpool_matrix(p.pooling[p.L - 1 - i], p.dec_cin[i] // p.edge_num[p.L - 1 - i])
+                         for i in range(p.L)]
+        self.params = {}
+        if params is not None:
+            self.load(params)
+
+    def load(self, params):
+        self.params = {k: v.detach().clone().float().requires_grad_(True) for k, v in params.items()
+                       if k in reference_param_shapes(self.plan)}
+
+    def trainable(self):
+        """Tensors in the reference's `.parameters()` order restricted to requires_grad."""
+        order = []
+        p = self.plan
+        for i in range(p.L):
+            order += ["enc.layers.%d.0.weight" % i, "enc.layers.%d.0.bias" % i]
+        for i in range(p.L):
+            order += ["enc.latent_enc_layers.%d.weight" % i, "enc.latent_enc_layers.%d.bias" % i]
+        for i in range(p.L):
+            order += [p.dec_conv_key(i) + ".weight"]
+            if p.dec_bias[i]:
+                order += [p.dec_conv_key(i) + ".bias"]
+        for i in range(p.L):
+            order += ["dec.latent_dec_layers.%d.weight" % i, "dec.latent_dec_layers.%d.bias" % i]
+        return [(n, self.params[n]) for n in order]
+
+    # -- encoder (seq_two_hier_sa_vae.py:142-166) --
+    def encode(self, x):
+        p, P = self.plan, self.params
+        zs, acts = [], []
+        for i in range(p.L):
+            x = skel_conv(x, P["enc.layers.%d.0.weight" % i], self.masks["enc.layers.%d.0.mask" % i],
+                          P["enc.layers.%d.0.bias" % i], p.strides[i], p.pad, p.pad_mode)
+            x = torch.matmul(self.pool_w[i], x)
+            x = F.leaky_relu(x, 0.2)
+            acts.append(x)
+            b = x.shape[0]
+            k_edges = x.shape[1] // p.ch_base[i + 1]
+            feat = x.reshape(b, k_edges, -1)
+            zs.append(F.linear(feat, P["enc.latent_enc_layers.%d.weight" % i], P["enc.latent_enc_layers.%d.bias" % i]))
+        return x, zs, acts
+
+    # -- decoder (seq_two_hier_sa_vae.py:260-294) --
+    def decode_feats(self, z_list):
+        p, P = self.plan, self.params
+        L = p.L
+        hier = []
+        for zi in range(L):
+            z = z_list[L - 1 - zi]
+            f = F.linear(z, P["dec.latent_dec_layers.%d.weight" % zi], P["dec.latent_dec_layers.%d.bias" % zi])
+            hier.append(f.reshape(z.shape[0], -1, p.dec_ts[zi]))
+        x = None
+        for i in range(L):
+            if i == 0:
+                x = hier[0]
+            elif i == L - 1:
+                b, _, t = x.shape
+                k_edges = p.edge_num[L - i]
+                x = torch.cat((x.reshape(b, k_edges, -1, t), hier[i].reshape(b, k_edges, -1, t)), dim=2).reshape(b, -1, t)
+            if p.dec_up[i]:
+                x = F.interpolate(x, scale_factor=2, mode=self.hp["upsampling"], align_corners=False)
+            x = torch.matmul(self.unpool_w[i], x)
+            ck = p.dec_conv_key(i)
+            bias = P.get(ck + ".bias") if p.dec_bias[i] else None
+            x = skel_conv(x, P[ck + ".weight"], self.masks[ck + ".mask"], bias, 1,
+                          p.pad, p.pad_mode)
+            if i != L - 1:
+                x = F.leaky_relu(x, 0.2)
+        return x
+
+    # -- decode tail (seq_two_hier_sa_vae.py:436-474) --
+    def decode(self, z_list):
+        out = self.decode_feats(z_list)                       # (B, 24*6, T)
+        b = out.shape[0]
+        T = self.plan.T
+        nj = self.hp["n_joints"]
+        dec = out.transpose(1, 2).reshape(b * T, nj, -1)
+        c6 = dec[:, :, :self.hp["output_dim"]]
+        R = rot6d_to_matrix(c6)
+        pos = fk_positions(R, self.parents, self.offsets)
+        return c6.reshape(b, T, nj, -1), R.reshape(b, T, nj, 3, 3), pos.reshape(b, T, nj, 3), out
+
+    @staticmethod
+    def kl(logvar, mu):
+        """seq_two_hier_sa_vae.py:425-428."""
+        return (-0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp(), dim=1)).mean()
+
+    def train_forward(self, data, iterations, eps_list, backward=True):
+        """seq_two_hier_sa_vae.py:335-417 with injected eps (one tensor per level, shape (B*k, d)).
+
+        Returns a dict with every intermediate the parity tests compare.
+        """
+        hp, p = self.hp, self.plan
+        r6, rmat = data[0].float(), data[1].float()
+        b, T, _ = r6.shape
+        nj = hp["n_joints"]
+        gt_pos = fk_positions(rmat.reshape(b * T, nj, 3, 3), self.parents, self.offsets).detach().reshape(b, T, -1)
+        x = r6.transpose(1, 2)
+        _, zs, _ = self.encode(x)
+        z_list, kls, mus, lvs = [], [], [], []
+        for zi, dist in enumerate(zs):
+            d = p.lat_dim[zi]
+            k_edges = dist.shape[1]
+            mu = dist[:, :, :d].reshape(-1, d)
+            lv = dist[:, :, d:].reshape(-1, d)
+            mus.append(mu)
+            lvs.append(lv)
+            if hp["kl_w"] != 0:
+                z = eps_list[zi] * torch.exp(0.5 * lv) + mu      # :419-423
+            else:
+                z = mu
+            z = z.reshape(b, k_edges, -1)
+            if zi == len(zs) - 1:
+                kl = self.kl(lv, mu)
+            elif zi == 0:
+                if iterations < hp["iteration_interval"]:
+                    kl = self.kl(lv.detach(), mu.detach())
+                    z = z.detach()
+                else:
+                    kl = self.kl(lv, mu)
+            else:
+                kl = torch.zeros(1)
+            z_list.append(z)
+            kls.append(kl)
+        c6, R, pos, dec_out = self.decode(z_list)
+        if backward:
+            dec_out.retain_grad()
+        l6 = ((c6.reshape(b, T, -1) - r6) ** 2).mean()
+        lr = ((R.reshape(b, T, -1) - rmat) ** 2).mean()
+        lp = ((pos.reshape(b, T, -1) - gt_pos) ** 2).mean()
+        l_kl = hp["kl_w"] * kls[-1] + hp["shallow_kl_w"] * kls[0]
+        total = hp["rec_6d_w"] * l6 + hp["rec_rot_w"] * lr + hp["rec_pose_w"] * lp + hp["kl_w"] * kls[-1] + \
+            hp["shallow_kl_w"] * kls[0]
+        if backward:
+            for t in self.params.values():
+                t.grad = None
+            total.backward()
+        return dict(total=total, kl=l_kl, rec_6d=l6, rec_rot=lr, rec_pose=lp, kl_list=kls, z_list=z_list,
+                    z_dist=zs, dec_out=dec_out, c6=c6, R=R, pos=pos, gt_pos=gt_pos)
+
+
+def make_adam(oracle, hp):
+    """trainer_motion_vae.py:29-33 — Adam over requires_grad params + StepLR."""
+    opt = torch.optim.Adam([t for _, t in oracle.trainable()], lr=hp["lr"], weight_decay=hp["weight_decay"])
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=hp["step_size"], gamma=hp["gamma"])
+    return opt, sched
+
+
+def synthetic_batch(b, T, seed=0, nj=24):
+    """SURVEY.md §8(d) synthetic AMASS-shaped batch: valid rotations from N(0,1) 6D draws."""
+    g = torch.Generator().manual_seed(seed)
+    raw = torch.randn(b * T, nj, 6, generator=g)
+    R = rot6d_to_matrix(raw)
+    r6 = matrix_to_rot6d(R).reshape(b, T, nj * 6)
+    rmat = R.reshape(b, T, nj * 9)
+    root_v = torch.randn(b, T, 3, generator=g)
+    z72 = torch.zeros(b, T, nj * 3)
+    return (r6, rmat, z72, z72.clone(), z72.clone(), z72.clone(), root_v)
+
+
+def level_eps(plan, b, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(b * plan.edge_num[i + 1], plan.lat_dim[i], generator=g) for i in range(plan.L)]

@@ -1,0 +1,46 @@
+"""Shared helpers for the parity tests (oracle side). Test-only."""
+import os
+import json
+
+import numpy as np
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CONFIGS = os.path.join(ROOT, "configs")
+
+CFG_FILES = {"len64": "len64_no_aug_hm_vae.yaml", "len8": "len8_data_aug_hm_vae.yaml"}
+
+
+def load_cfg(tag):
+    with open(os.path.join(CONFIGS, CFG_FILES[tag])) as f:
+        return yaml.safe_load(f)
+
+
+def load_model_golden(tag):
+    g = np.load(os.path.join(GOLDEN, "model_%s.npz" % tag))
+    meta = json.load(open(os.path.join(GOLDEN, "model_meta.json")))[tag]
+    return g, meta
+
+
+def golden_batch(g):
+    r6 = torch.from_numpy(g["in_r6"])
+    rmat = torch.from_numpy(g["in_rmat"])
+    b, T, _ = r6.shape
+    z72 = torch.zeros(b, T, 72)
+    return (r6, rmat, z72, z72.clone(), z72.clone(), z72.clone(), torch.from_numpy(g["in_root_v"]))
+
+
+def golden_eps(g):
+    return [torch.from_numpy(g["eps%d" % i]) for i in range(4)]
+
+
+def offsets():
+    return np.load(os.path.join(GOLDEN, "skeleton_offsets.npy"))
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))

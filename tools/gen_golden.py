@@ -1,0 +1,238 @@
+"""Generate tests/golden/*.npz|json by running the UNMODIFIED reference on CPU (build container only).
+
+    python tools/gen_golden.py            # writes into tests/golden/
+
+What is stored is data only: inputs, injected eps, and the reference's outputs / gradients /
+post-Adam parameters (sampled for the big tensors).  Weights are NOT stored: both sides rebuild them
+from the name-seeded recipe `oracle.hmvae_oracle.name_seeded_params` and load them through the
+reference's own state_dict keys.
+"""
+import os
+import sys
+import json
+import zlib
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+import ref_harness as H  # noqa: E402
+from oracle import hmvae_oracle as O  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def sample_idx(name, numel, n=64):
+    rng = np.random.default_rng(zlib.crc32(("idx:" + name).encode()))
+    return rng.integers(0, numel, size=min(n, numel))
+
+
+def summarize_grads(named, store, prefix):
+    none = []
+    for name, p in named:
+        if p.grad is None:
+            none.append(name)
+            continue
+        g = p.grad.detach().reshape(-1).numpy()
+        store[prefix + name + "|norm"] = np.float64(np.linalg.norm(g.astype(np.float64)))
+        if g.size <= 20000:
+            store[prefix + name + "|full"] = g.copy()
+        else:
+            idx = sample_idx(name, g.size)
+            store[prefix + name + "|idx"] = idx
+            store[prefix + name + "|val"] = g[idx].copy()
+    return none
+
+
+def topology_dump(ref_skel, parents_json):
+    edges = ref_skel.get_edges(parents_json)
+    out = {"edges0": [list(e) for e in edges], "levels": []}
+    cur = edges
+    for lvl in range(4):
+        nb = ref_skel.find_neighbor(cur, 2)
+        pool = ref_skel.SkeletonPool(cur, "mean", 3, last_pool=(lvl == 3))
+        out["levels"].append({"neighbours": nb, "seq_list": pool.seq_list, "pooling_list": pool.pooling_list,
+                              "new_edges": [list(e) for e in pool.new_edges]})
+        if lvl < 3:
+            cur = pool.new_edges
+    return out
+
+
+def fk_rot_golden(ref_tools, ref_fk_mod):
+    g = torch.Generator().manual_seed(123)
+    n = 32
+    r6 = torch.randn(n, 24, 6, generator=g)
+    r6[0, 0] = 0.0                                            # zero vector -> eps clamp, zero matrix
+    r6[1, 3, 3:6] = r6[1, 3, 0:3] * 2.0                       # parallel a,b -> z = 0
+    r6[2, 5, 3:6] = r6[2, 5, 0:3] * (1.0 + 1e-4) + 1e-5       # near-parallel
+    r6[3] = r6[3] * 1e-3                                      # tiny magnitude
+    r6[4] = r6[4] * 1e3                                       # huge magnitude
+    jj = torch.arange(24).float()[:, None] * 6 + torch.arange(6).float()[None, :]
+    r6[5] = torch.sin(0.37 * jj + 0.11)                       # SURVEY §7 analytic anchor input
+    wR = torch.randn(n, 24, 3, 3, generator=g)
+    wP = torch.randn(n, 24, 3, generator=g)
+    x = r6.clone().requires_grad_(True)
+    R = ref_tools.rotation_matrix_from_ortho6d(x)
+    fk = ref_fk_mod.ForwardKinematicsLayer()
+    P = fk(R)
+    P6 = fk(x)                                                # 6D input path of the layer
+    ((R * wR).sum() + (P * wP).sum()).backward()
+    d6 = x.grad.clone()
+    # FK-only backward w.r.t. rotation matrices
+    Rin = R.detach().clone().requires_grad_(True)
+    P2 = fk(Rin)
+    (P2 * wP).sum().backward()
+    # anchor: d(sum P^2)/d r6 for sample 5
+    xa = r6[5:6].clone().requires_grad_(True)
+    Pa = fk(ref_tools.rotation_matrix_from_ortho6d(xa))
+    (Pa ** 2).sum().backward()
+    ident = torch.eye(3)[None, None].repeat(1, 24, 1, 1)
+    rest = fk(ident)
+    return dict(r6=r6.numpy(), wR=wR.numpy(), wP=wP.numpy(), R=R.detach().numpy(), P=P.detach().numpy(),
+                P_from6d=P6.detach().numpy(), d6=d6.numpy(), dR_fkonly=Rin.grad.numpy(),
+                anchor_d6=xa.grad.numpy(), rest=rest.numpy())
+
+
+def model_golden(cfg_name, B, seed):
+    import trainer_motion_vae as RT
+    cfg = yaml.safe_load(open(os.path.join(H.REF_ROOT, "configs", cfg_name)))
+    plan = O.Plan(cfg)
+    tr = RT.Trainer(cfg)
+    model = tr.model
+    # name-seeded weights through the reference's own state_dict keys
+    seeded = O.name_seeded_params(plan)
+    sd = model.state_dict()
+    for k, v in seeded.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
+        mk = k.replace("weight", "mask")
+        if v.dim() == 3:
+            assert torch.equal((sd[mk] == 0), (v == 0) | (sd[mk] == 0))
+        sd[k] = v.clone()
+    model.load_state_dict(sd)
+    store = {}
+    meta = {"cfg": cfg_name, "B": B, "state_dict_keys": list(sd.keys()),
+            "trainable_order": [n for n, p in model.named_parameters() if p.requires_grad],
+            "all_param_order": [n for n, p in model.named_parameters()]}
+    T = cfg["train_seq_len"]
+    data = O.synthetic_batch(B, T, seed=seed)
+    eps = O.level_eps(plan, B, seed=seed + 1)
+    store["in_r6"] = data[0].numpy()
+    store["in_rmat"] = data[1].numpy()
+    store["in_root_v"] = data[6].numpy()
+    for i, e in enumerate(eps):
+        store["eps%d" % i] = e.numpy()
+
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    # mask / pool / unpool constants: record density + checksum so the oracle's derivation is pinned
+    trainable_names = set(n for n, _ in named)
+    for k, v in sd.items():
+        if k.startswith("dec.enc."):
+            continue
+        if k not in trainable_names:
+            store["const|" + k + "|sum"] = np.float64(v.double().sum().item())
+            store["const|" + k + "|wsum"] = np.float64(
+                (v.double().reshape(-1) * torch.arange(1, v.numel() + 1).double() % 7.0).sum().item())
+
+    for phase, it in (("p1", 0), ("p2", cfg["iteration_interval"])):
+        # capture intermediates with hooks on the reference modules
+        caps = {}
+        hooks = [model.enc.register_forward_hook(lambda m, i, o: caps.__setitem__("enc", o)),
+                 model.dec.register_forward_hook(lambda m, i, o: caps.__setitem__("dec", o))]
+        tr.gen_opt.zero_grad()
+        orig_decode = model._decode
+
+        def cap_decode(z_list, *a, **k):
+            r = orig_decode(z_list, *a, **k)
+            caps["decode"] = r
+            caps["z_list"] = z_list
+            return r
+
+        model._decode = cap_decode
+        dec_grad = {}
+
+        def dec_hook(m, i, o):
+            o.register_hook(lambda g: dec_grad.__setitem__("g", g.clone()))
+
+        hooks.append(model.dec.register_forward_hook(dec_hook))
+        with H.EpsInjector([e.clone() for e in eps]):
+            ret = model(data, cfg, it)
+        model._decode = orig_decode
+        for h in hooks:
+            h.remove()
+        l_total, l_kl, l6, lrm, lp = [float(x) for x in ret[:5]]
+        store[phase + "|losses"] = np.array([l_total, l_kl, l6, lrm, lp], dtype=np.float64)
+        store[phase + "|kl_list"] = np.array([float(x) for x in ret[9]], dtype=np.float64)
+        latent, zs = caps["enc"]
+        for i, z in enumerate(zs):
+            store[phase + "|z_dist%d" % i] = z.detach().numpy()
+        store[phase + "|latent"] = latent.detach().numpy()
+        for i, z in enumerate(caps["z_list"]):
+            store[phase + "|z%d" % i] = z.detach().numpy()
+        store[phase + "|dec_out"] = caps["dec"].detach().numpy()
+        c6, R, pos = caps["decode"][:3]
+        store[phase + "|R"] = R.detach().numpy()
+        store[phase + "|pos"] = pos.detach().numpy()
+        store[phase + "|d_dec_out"] = dec_grad["g"].numpy()
+        none = summarize_grads(named, store, phase + "|grad|")
+        meta[phase + "_none_grad"] = none
+
+    # two full Trainer.gen_update steps (phase 1) from the seeded state: losses + sampled params
+    model.load_state_dict(sd)
+    tr2 = RT.Trainer(cfg)
+    tr2.model.load_state_dict(sd)
+    steps = []
+    for s in range(2):
+        with H.EpsInjector([e.clone() for e in eps]):
+            out = tr2.gen_update(data, cfg, s, False)
+        steps.append([float(x) for x in out])
+    store["upd|returns"] = np.array(steps, dtype=np.float64)
+    for n, p in tr2.model.named_parameters():
+        if not p.requires_grad:
+            continue
+        v = p.detach().reshape(-1).numpy()
+        idx = sample_idx("upd:" + n, v.size)
+        store["upd|" + n + "|idx"] = idx
+        store["upd|" + n + "|val"] = v[idx].copy()
+        store["upd|" + n + "|delta"] = (v[idx].astype(np.float64) - seeded[n].reshape(-1).numpy()[idx].astype(np.float64))
+    meta["lr_after_2"] = tr2.gen_opt.param_groups[0]["lr"]
+    # sampled branch of test(): decoder-only from given z-list (config 4 semantics)
+    g = torch.Generator().manual_seed(seed + 7)
+    zl = [torch.randn(B, plan.edge_num[i + 1], plan.lat_dim[i], generator=g) for i in range(plan.L)]
+    with torch.no_grad():
+        c6, R, pos = tr2.model._decode(zl)[:3]
+    for i, z in enumerate(zl):
+        store["samp|z%d" % i] = z.numpy()
+    store["samp|c6"] = c6.numpy()
+    store["samp|R"] = R.numpy()
+    store["samp|pos"] = pos.numpy()
+    return store, meta
+
+
+def main():
+    H.install()
+    import skeleton as ref_skel
+    import my_tools as ref_tools
+    import fk_layer as ref_fk_mod
+    os.makedirs(OUT, exist_ok=True)
+    topo = topology_dump(ref_skel, os.path.join(H.REF_ROOT, "utils/data/joint24_parents.json"))
+    json.dump(topo, open(os.path.join(OUT, "topology.json"), "w"))
+    np.savez_compressed(os.path.join(OUT, "fk_rot6d.npz"), **fk_rot_golden(ref_tools, ref_fk_mod))
+    metas = {}
+    for tag, cfg, B, seed in (("len64", "len64_no_aug_hm_vae.yaml", 2, 11), ("len8", "len8_data_aug_hm_vae.yaml", 4, 21)):
+        store, meta = model_golden(cfg, B, seed)
+        np.savez_compressed(os.path.join(OUT, "model_%s.npz" % tag), **store)
+        metas[tag] = meta
+    json.dump(metas, open(os.path.join(OUT, "model_meta.json"), "w"), indent=1)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
