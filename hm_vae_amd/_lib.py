@@ -1,0 +1,130 @@
+"""ctypes binding of libhmvae_hip.so (C ABI in include/hmvae.h).
+
+There is NO fallback: if the library is missing or a call fails, an exception is raised.  The library
+is built in-tree by `hm_vae_amd.build` (hipcc, gfx950) and travels to the GPU box with the repo.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import build as _build
+
+_c_float_p = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+_f32 = C.c_float
+_ptr = C.c_void_p
+
+
+class HmvaeError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("src", _ptr), ("dst", _ptr), ("wp", _ptr), ("bias", _ptr), ("bias_idx", _ptr), ("g_nc4", _ptr), ("g_woff", _ptr),
+                ("g_choff", _ptr), ("chan_rows", _ptr), ("dst_rows", _ptr), ("p_off", _ptr), ("p_len", _ptr),
+                ("pairs", _ptr), ("n_groups", _i32), ("mt", _i32), ("kt", _i32), ("n_pos", _i32), ("bp", _i32),
+                ("src_ts", _i32), ("dst_ts", _i32), ("flags", _i32), ("slope", _f32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("dz", _ptr), ("x", _ptr), ("slab", _ptr), ("tile_g", _ptr), ("tile_col0", _ptr), ("g_ncols", _ptr),
+                ("g_choff", _ptr), ("chan_rows", _ptr), ("dz_rows", _ptr), ("n_tiles", _i32), ("n_groups", _i32),
+                ("mt", _i32), ("kt", _i32), ("n_split", _i32), ("t_dst", _i32), ("t_src", _i32), ("stride", _i32),
+                ("pad", _i32), ("pad_mode", _i32), ("bp", _i32), ("dz_ts", _i32), ("x_ts", _i32)]
+
+
+class WreduceDesc(C.Structure):
+    _fields_ = [("slab", _ptr), ("dense", _ptr), ("tile_g", _ptr), ("tile_col0", _ptr), ("g_ncols", _ptr),
+                ("g_choff", _ptr), ("chan_id", _ptr), ("row_id", _ptr), ("g_nc4", _ptr), ("g_okoff", _ptr), ("pair_ok", _ptr),
+                ("n_tiles", _i32), ("mt", _i32), ("kt", _i32), ("n_split", _i32), ("row_stride", _i32), ("chan_stride", _i32), ("accumulate", _i32)]
+
+
+class AdamTensor(C.Structure):
+    _fields_ = [("p", _ptr), ("g", _ptr), ("m", _ptr), ("v", _ptr), ("n", _i64)]
+
+
+FLAG_LEAKY = 1
+FLAG_ACCUM = 2
+PAD_REFLECT = 0
+PAD_ZEROS = 1
+
+_SIGS = {
+    "hmvae_version": ([], _i32),
+    "hmvae_error_string": ([_i32], C.c_char_p),
+    "hmvae_gather_gemm": ([C.POINTER(GemmDesc), _ptr], _i32),
+    "hmvae_wgrad_gemm": ([C.POINTER(WgradDesc), _ptr], _i32),
+    "hmvae_wgrad_reduce": ([C.POINTER(WreduceDesc), _ptr], _i32),
+    "hmvae_pack_weights": ([_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
+    "hmvae_pool_leaky_fwd": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),
+    "hmvae_pool_leaky_bwd": ([_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),
+    "hmvae_upsample_unpool_fwd": ([_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
+    "hmvae_upsample_unpool_bwd": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
+    "hmvae_leaky_bwd": ([_ptr, _ptr, _ptr, _i64, _f32, _ptr], _i32),
+    "hmvae_row_sums": ([_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
+    "hmvae_aos_to_soa": ([_ptr, _ptr, _i32, _i32, _i32, _i32, _ptr], _i32),
+    "hmvae_soa_to_aos": ([_ptr, _ptr, _i32, _i32, _i32, _i32, _ptr], _i32),
+    "hmvae_reparam_kl_fwd": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
+    "hmvae_reparam_kl_bwd": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),
+    "hmvae_fk_fwd": ([_ptr, _i32, _ptr, _i64, C.POINTER(_i32), _i32, _i64, _ptr, _ptr, _ptr], _i32),
+    "hmvae_fk_bwd": ([_ptr, _i32, _ptr, _i64, C.POINTER(_i32), _i32, _i64, _ptr, _ptr, _ptr, _ptr], _i32),
+    "hmvae_decode_tail_loss": ([_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _f32, _f32, _f32, _ptr, _ptr,
+                                C.POINTER(_i32), _ptr], _i32),
+    "hmvae_decode_tail_fwd": ([_ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr, _ptr, _ptr], _i32),
+    "hmvae_finalize_sums": ([_ptr, _i32, _i32, _i32, _f32, _ptr, _ptr], _i32),
+    "hmvae_adam_step": ([_ptr, _i32, _i64, _ptr, _ptr, _f32, _f32, _f32, _f32, _ptr], _i32),
+}
+
+EXPORTS = sorted(_SIGS)
+_lib = None
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (building first if the sources are newer) and type the library.  Raises on any problem."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        if os.path.exists("/opt/rocm/bin/hipcc") or os.environ.get("HIPCC"):
+            _build.build(verbose=False)
+        else:
+            raise HmvaeError("libhmvae_hip.so not found at %s and no hipcc to build it; there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    for name, (args, res) in _SIGS.items():
+        fn = getattr(lib, name)      # AttributeError if an export is missing
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().hmvae_error_string(code).decode()
+        raise HmvaeError("%s failed: %s (%d)" % (what or "hmvae call", msg, code))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be contiguous fp32/int32 on a HIP device."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HmvaeError("hm_vae_amd kernels need device tensors (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise HmvaeError("non-contiguous tensor passed to a HIP kernel")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise HmvaeError("no HIP device visible: hm_vae_amd has no CPU path (use oracle/ only for checking)")

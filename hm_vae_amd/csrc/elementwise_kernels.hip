@@ -1,0 +1,436 @@
+// elementwise_kernels.hip — HBM-bound SoA kernels of the hm-vae hot path (gfx950).
+//
+// Reference code replaced (paths relative to the reference root):
+//   skeleton.py:228-231   SkeletonPool.forward   (dense matmul with a constant 1/len matrix)
+//   skeleton.py:258-261   SkeletonUnpool.forward (dense matmul with a constant 0/1 matrix)
+//   seq_two_hier_sa_vae.py:129,256  nn.LeakyReLU(0.2);  :235-240  nn.Upsample(x2, linear)
+//   seq_two_hier_sa_vae.py:419-428  reparametrize, kl_loss;  :408-411 total loss
+//   trainer_motion_vae.py:29-31,92  torch.optim.Adam step
+// All activations are [row][Bp] float with the batch innermost; every thread moves 16 bytes.
+#include <hip/hip_runtime.h>
+#include "hmvae.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int grid_for(long long n_items, int per_block = 256, int cap = 8192) {
+    long long nb = (n_items + per_block - 1) / per_block;
+    if (nb < 1) nb = 1;
+    if (nb > cap) nb = cap;
+    return (int)nb;
+}
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH)
+
+__device__ __forceinline__ f32x4 leaky4(f32x4 v, float slope) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+    return v;
+}
+
+// ---------------- pool (+LeakyReLU) ----------------
+__global__ __launch_bounds__(256) void pool_leaky_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              const int* __restrict__ e1, const int* __restrict__ e2,
+                                                              int n_out_edges, int cht, int bq, float slope) {
+    const long long total = (long long)n_out_edges * cht * bq;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int q = (int)(idx % bq);
+        const long long row = idx / bq;
+        const int e = (int)(row / cht);
+        const int rem = (int)(row - (long long)e * cht);
+        const int a = e1[e], b = e2[e];
+        f32x4 v = *(const f32x4*)(in + ((size_t)a * cht + rem) * (bq * 4) + q * 4);
+        if (b >= 0) {
+            f32x4 w = *(const f32x4*)(in + ((size_t)b * cht + rem) * (bq * 4) + q * 4);
+            v = (v + w) * 0.5f;
+        }
+        *(f32x4*)(out + (size_t)row * (bq * 4) + q * 4) = leaky4(v, slope);
+    }
+}
+
+extern "C" int hmvae_pool_leaky_fwd(const float* in, float* out, const int32_t* src_e1, const int32_t* src_e2,
+                                    int32_t n_out_edges, int32_t ch, int32_t T, int32_t bp, float slope,
+                                    hmvae_stream_t stream) {
+    if (!in || !out || bp <= 0 || (bp & 3)) return HMVAE_ERR_ARG;
+    const long long total = (long long)n_out_edges * ch * T * (bp / 4);
+    hipLaunchKernelGGL(pool_leaky_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, src_e1,
+                       src_e2, n_out_edges, ch * T, bp / 4, slope);
+    return LAUNCH_OK();
+}
+
+__global__ __launch_bounds__(256) void pool_leaky_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ outv,
+                                                              float* __restrict__ din, const int* __restrict__ dst_e,
+                                                              const float* __restrict__ w_e, int n_in_edges, int cht,
+                                                              int bq, float slope) {
+    const long long total = (long long)n_in_edges * cht * bq;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int q = (int)(idx % bq);
+        const long long row = idx / bq;
+        const int e = (int)(row / cht);
+        const int rem = (int)(row - (long long)e * cht);
+        const size_t o = ((size_t)dst_e[e] * cht + rem) * (bq * 4) + q * 4;
+        const f32x4 g = *(const f32x4*)(dout + o);
+        const f32x4 y = *(const f32x4*)(outv + o);
+        const float w = w_e[e];
+        f32x4 r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = g[k] * (y[k] > 0.f ? 1.f : slope) * w;
+        *(f32x4*)(din + (size_t)row * (bq * 4) + q * 4) = r;
+    }
+}
+
+extern "C" int hmvae_pool_leaky_bwd(const float* dout, const float* out, float* din, const int32_t* dst_e,
+                                    const float* w_e, int32_t n_in_edges, int32_t ch, int32_t T, int32_t bp, float slope,
+                                    hmvae_stream_t stream) {
+    if (!dout || !out || !din || bp <= 0 || (bp & 3)) return HMVAE_ERR_ARG;
+    const long long total = (long long)n_in_edges * ch * T * (bp / 4);
+    hipLaunchKernelGGL(pool_leaky_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dout, out, din,
+                       dst_e, w_e, n_in_edges, ch * T, bp / 4, slope);
+    return LAUNCH_OK();
+}
+
+// ---------------- upsample (x2 linear, align_corners=False) + unpool ----------------
+__global__ __launch_bounds__(256) void up_unpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             const int* __restrict__ src_e, int n_out_edges, int ch,
+                                                             int t_in, int up, int bq) {
+    const int t_out = up ? 2 * t_in : t_in;
+    const long long total = (long long)n_out_edges * ch * t_out * bq;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int q = (int)(idx % bq);
+        const long long row = idx / bq;
+        const int t = (int)(row % t_out);
+        const long long ec = row / t_out;
+        const int c = (int)(ec % ch);
+        const int e = (int)(ec / ch);
+        const float* base = in + ((size_t)src_e[e] * ch + c) * t_in * (bq * 4) + q * 4;
+        f32x4 v;
+        if (!up) {
+            v = *(const f32x4*)(base + (size_t)t * (bq * 4));
+        } else {
+            const int i = t >> 1;
+            int i0, i1;
+            float w0, w1;
+            if (t & 1) {
+                i0 = i;
+                i1 = i + 1 < t_in ? i + 1 : t_in - 1;
+                w0 = 0.75f;
+                w1 = 0.25f;
+            } else {
+                i0 = i > 0 ? i - 1 : 0;
+                i1 = i;
+                w0 = 0.25f;
+                w1 = 0.75f;
+            }
+            const f32x4 a = *(const f32x4*)(base + (size_t)i0 * (bq * 4));
+            const f32x4 b = *(const f32x4*)(base + (size_t)i1 * (bq * 4));
+            v = a * w0 + b * w1;
+        }
+        *(f32x4*)(out + (size_t)row * (bq * 4) + q * 4) = v;
+    }
+}
+
+extern "C" int hmvae_upsample_unpool_fwd(const float* in, float* out, const int32_t* src_e, int32_t n_out_edges,
+                                         int32_t ch, int32_t T_in, int32_t up, int32_t bp, hmvae_stream_t stream) {
+    if (!in || !out || bp <= 0 || (bp & 3)) return HMVAE_ERR_ARG;
+    const long long total = (long long)n_out_edges * ch * (up ? 2 * T_in : T_in) * (bp / 4);
+    hipLaunchKernelGGL(up_unpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, src_e,
+                       n_out_edges, ch, T_in, up, bp / 4);
+    return LAUNCH_OK();
+}
+
+__global__ __launch_bounds__(256) void up_unpool_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din,
+                                                             const int* __restrict__ fine_off,
+                                                             const int* __restrict__ fine_list, int n_in_edges, int ch,
+                                                             int t_in, int up, int bq) {
+    const int t_out = up ? 2 * t_in : t_in;
+    const long long total = (long long)n_in_edges * ch * t_in * bq;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int q = (int)(idx % bq);
+        const long long row = idx / bq;
+        const int i = (int)(row % t_in);
+        const long long ec = row / t_in;
+        const int c = (int)(ec % ch);
+        const int e = (int)(ec / ch);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = fine_off[e]; k < fine_off[e + 1]; ++k) {
+            const float* base = dout + ((size_t)fine_list[k] * ch + c) * t_out * (bq * 4) + q * 4;
+            if (!up) {
+                acc += *(const f32x4*)(base + (size_t)i * (bq * 4));
+            } else {
+                // out[2i] = .25 in[i-1] + .75 in[i] (in[-1]:=in[0]);  out[2i+1] = .75 in[i] + .25 in[i+1] (in[T]:=in[T-1])
+                const f32x4 e0 = *(const f32x4*)(base + (size_t)(2 * i) * (bq * 4));
+                const f32x4 o0 = *(const f32x4*)(base + (size_t)(2 * i + 1) * (bq * 4));
+                f32x4 s = (e0 + o0) * 0.75f;
+                if (i + 1 < t_in) s += *(const f32x4*)(base + (size_t)(2 * i + 2) * (bq * 4)) * 0.25f;
+                else s += o0 * 0.25f;
+                if (i > 0) s += *(const f32x4*)(base + (size_t)(2 * i - 1) * (bq * 4)) * 0.25f;
+                else s += e0 * 0.25f;
+                acc += s;
+            }
+        }
+        *(f32x4*)(din + (size_t)row * (bq * 4) + q * 4) = acc;
+    }
+}
+
+extern "C" int hmvae_upsample_unpool_bwd(const float* dout, float* din, const int32_t* fine_off, const int32_t* fine_list,
+                                         int32_t n_in_edges, int32_t ch, int32_t T_in, int32_t up, int32_t bp,
+                                         hmvae_stream_t stream) {
+    if (!dout || !din || bp <= 0 || (bp & 3)) return HMVAE_ERR_ARG;
+    const long long total = (long long)n_in_edges * ch * T_in * (bp / 4);
+    hipLaunchKernelGGL(up_unpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dout, din,
+                       fine_off, fine_list, n_in_edges, ch, T_in, up, bp / 4);
+    return LAUNCH_OK();
+}
+
+// ---------------- LeakyReLU backward from the output ----------------
+__global__ __launch_bounds__(256) void leaky_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ outv,
+                                                         float* __restrict__ dy, long long n4, float slope) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += (long long)gridDim.x * 256) {
+        const f32x4 g = ((const f32x4*)dout)[idx];
+        const f32x4 y = ((const f32x4*)outv)[idx];
+        f32x4 r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = g[k] * (y[k] > 0.f ? 1.f : slope);
+        ((f32x4*)dy)[idx] = r;
+    }
+}
+
+extern "C" int hmvae_leaky_bwd(const float* dout, const float* out, float* dy, int64_t n, float slope,
+                               hmvae_stream_t stream) {
+    if (!dout || !out || !dy || n <= 0 || (n & 3)) return HMVAE_ERR_ARG;
+    hipLaunchKernelGGL(leaky_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dout, out, dy,
+                       (long long)(n / 4), slope);
+    return LAUNCH_OK();
+}
+
+// ---------------- block reduction helper ----------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// returns the block total in thread 0 (256 threads)
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---------------- row sums (bias gradients) ----------------
+__global__ __launch_bounds__(256) void row_sums_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                        const int* __restrict__ rows, int rows_per_out, int row_step,
+                                                        int n_cols, int accumulate) {
+    __shared__ float sh[4];
+    const int o = blockIdx.x;
+    const int base = rows[o];
+    float s = 0.f;
+    const int nq = n_cols >> 2;
+    for (int k = 0; k < rows_per_out; ++k) {
+        const f32x4* p = (const f32x4*)(src + (size_t)(base + k * row_step) * n_cols);
+        for (int q = threadIdx.x; q < nq; q += 256) {
+            const f32x4 v = p[q];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    }
+    const float tot = block_sum256(s, sh);
+    if (threadIdx.x == 0) dst[o] = accumulate ? dst[o] + tot : tot;
+}
+
+// rows[i] = first row of output i; rows_per_out rows spaced `row_step` apart are summed.
+extern "C" int hmvae_row_sums(const float* src, float* dst, const int32_t* rows, int32_t n_out, int32_t rows_per_out,
+                              int32_t row_step, int32_t n_cols, int32_t accumulate, hmvae_stream_t stream) {
+    if (!src || !dst || !rows || n_out <= 0 || rows_per_out <= 0 || (n_cols & 3)) return HMVAE_ERR_ARG;
+    hipLaunchKernelGGL(row_sums_kernel, dim3(n_out), dim3(256), 0, (hipStream_t)stream, src, dst, rows, rows_per_out,
+                       row_step, n_cols, accumulate);
+    return LAUNCH_OK();
+}
+
+// ---------------- AoS (B,T,C) <-> SoA (C,T,Bp) ----------------
+__global__ __launch_bounds__(256) void aos_to_soa_kernel(const float* __restrict__ aos, float* __restrict__ soa, int B,
+                                                          int T, int C, int bp) {
+    __shared__ float tile[64][65];
+    const int t = blockIdx.z;
+    const int b0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int b = b0 + r, c = c0 + tx;
+        tile[r][tx] = (b < B && c < C) ? aos[((size_t)b * T + t) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, b = b0 + tx;
+        if (c < C && b < bp) soa[((size_t)c * T + t) * bp + b] = tile[tx][r];
+    }
+}
+
+extern "C" int hmvae_aos_to_soa(const float* aos, float* soa, int32_t B, int32_t T, int32_t C, int32_t bp,
+                                hmvae_stream_t stream) {
+    if (!aos || !soa || B <= 0 || bp < B || (bp & 63) || T <= 0 || T > 65535) return HMVAE_ERR_ARG;
+    dim3 grid(bp / 64, (C + 63) / 64, T);
+    hipLaunchKernelGGL(aos_to_soa_kernel, grid, dim3(256), 0, (hipStream_t)stream, aos, soa, B, T, C, bp);
+    return LAUNCH_OK();
+}
+
+__global__ __launch_bounds__(256) void soa_to_aos_kernel(const float* __restrict__ soa, float* __restrict__ aos, int B,
+                                                          int T, int C, int bp) {
+    __shared__ float tile[64][65];
+    const int t = blockIdx.z;
+    const int b0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, b = b0 + tx;
+        tile[r][tx] = (c < C && b < bp) ? soa[((size_t)c * T + t) * bp + b] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int b = b0 + r, c = c0 + tx;
+        if (b < B && c < C) aos[((size_t)b * T + t) * C + c] = tile[tx][r];
+    }
+}
+
+extern "C" int hmvae_soa_to_aos(const float* soa, float* aos, int32_t B, int32_t T, int32_t C, int32_t bp,
+                                hmvae_stream_t stream) {
+    if (!aos || !soa || B <= 0 || bp < B || (bp & 63) || T <= 0 || T > 65535) return HMVAE_ERR_ARG;
+    dim3 grid(bp / 64, (C + 63) / 64, T);
+    hipLaunchKernelGGL(soa_to_aos_kernel, grid, dim3(256), 0, (hipStream_t)stream, soa, aos, B, T, C, bp);
+    return LAUNCH_OK();
+}
+
+// ---------------- reparametrize + KL ----------------
+// grid: (bp/256 rounded up, k_edges); thread = one batch column of one edge
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* __restrict__ dist, const float* __restrict__ eps,
+                                                              float* __restrict__ z, float* __restrict__ kl_partial,
+                                                              int k_edges, int dl, int B, int bp, int sample) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.y;
+    float kl = 0.f;
+    if (b < bp) {
+        const bool live = b < B;
+        for (int j = 0; j < dl; ++j) {
+            const float mu = dist[(size_t)(e * 2 * dl + j) * bp + b];
+            const float lv = dist[(size_t)(e * 2 * dl + dl + j) * bp + b];
+            float zz = mu;
+            if (sample && live) zz = eps[((size_t)b * k_edges + e) * dl + j] * expf(0.5f * lv) + mu;
+            z[(size_t)(e * dl + j) * bp + b] = live ? zz : 0.f;
+            if (live) kl += 1.f + lv - mu * mu - expf(lv);
+        }
+        kl *= -0.5f;
+    }
+    const float tot = block_sum256(kl, sh);
+    if (threadIdx.x == 0) kl_partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
+extern "C" int hmvae_reparam_kl_fwd(const float* dist, const float* eps, float* z, float* kl_partial, int32_t k_edges,
+                                    int32_t d, int32_t B, int32_t bp, int32_t sample, hmvae_stream_t stream) {
+    if (!dist || !z || !kl_partial || (sample && !eps) || bp < B) return HMVAE_ERR_ARG;
+    dim3 grid((bp + 255) / 256, k_edges);
+    hipLaunchKernelGGL(reparam_kl_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dist, eps, z, kl_partial, k_edges,
+                       d, B, bp, sample);
+    return LAUNCH_OK();
+}
+
+__global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(const float* __restrict__ dist, const float* __restrict__ eps,
+                                                              const float* __restrict__ dz, float* __restrict__ ddist,
+                                                              int k_edges, int dl, int B, int bp, int use_dz,
+                                                              float kl_scale) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.y;
+    if (b >= bp) return;
+    const bool live = b < B;
+    for (int j = 0; j < dl; ++j) {
+        const size_t rmu = (size_t)(e * 2 * dl + j) * bp + b;
+        const size_t rlv = (size_t)(e * 2 * dl + dl + j) * bp + b;
+        float gmu = 0.f, glv = 0.f;
+        if (live) {
+            const float mu = dist[rmu], lv = dist[rlv];
+            gmu = kl_scale * mu;
+            glv = kl_scale * 0.5f * (expf(lv) - 1.f);
+            if (use_dz) {
+                const float g = dz[(size_t)(e * dl + j) * bp + b];
+                gmu += g;
+                if (eps) glv += g * eps[((size_t)b * k_edges + e) * dl + j] * 0.5f * expf(0.5f * lv);
+            }
+        }
+        ddist[rmu] = gmu;
+        ddist[rlv] = glv;
+    }
+}
+
+extern "C" int hmvae_reparam_kl_bwd(const float* dist, const float* eps, const float* dz, float* ddist, int32_t k_edges,
+                                    int32_t d, int32_t B, int32_t bp, int32_t use_dz, float kl_scale,
+                                    hmvae_stream_t stream) {
+    if (!dist || !ddist || (use_dz && !dz) || bp < B) return HMVAE_ERR_ARG;
+    dim3 grid((bp + 255) / 256, k_edges);
+    hipLaunchKernelGGL(reparam_kl_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dist, eps, dz, ddist, k_edges, d, B,
+                       bp, use_dz, kl_scale);
+    return LAUNCH_OK();
+}
+
+// ---------------- fixed-order final sums ----------------
+__global__ __launch_bounds__(256) void finalize_sums_kernel(const float* __restrict__ partial, int n_partial, int stride,
+                                                             int k, float scale, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_partial; i += 256) s += partial[(size_t)i * stride + k];
+    const float tot = block_sum256(s, sh);
+    if (threadIdx.x == 0) out[0] = tot * scale;
+}
+
+extern "C" int hmvae_finalize_sums(const float* partial, int32_t n_partial, int32_t stride, int32_t k, float scale,
+                                   float* out, hmvae_stream_t stream) {
+    if (!partial || !out || n_partial <= 0) return HMVAE_ERR_ARG;
+    hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n_partial, stride, k,
+                       scale, out);
+    return LAUNCH_OK();
+}
+
+// ---------------- Adam ----------------
+__global__ __launch_bounds__(256) void adam_kernel(const hmvae_adam_tensor* __restrict__ tab,
+                                                    const float* __restrict__ lr_dev, const int* __restrict__ step_dev,
+                                                    float b1, float b2, float eps, float wd) {
+    const hmvae_adam_tensor t = tab[blockIdx.y];
+    const int step = step_dev[0];
+    // torch computes the bias corrections in double on the host; keep them in double here
+    const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
+    const float step_size = lr_dev[0] / bc1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < t.n; i += (long long)gridDim.x * 256) {
+        const float p = t.p[i];
+        float g = t.g[i];
+        g = g + wd * p;                                   // torch: grad.add(param, alpha=weight_decay)
+        float m = t.m[i];
+        m = m + (g - m) * (1.f - b1);                     // torch: exp_avg.lerp_(grad, 1 - beta1)
+        float v = t.v[i];
+        v = v * b2 + (1.f - b2) * g * g;                  // torch: exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        t.m[i] = m;
+        t.v[i] = v;
+        t.p[i] = p - step_size * (m / denom);             // torch: param.addcdiv_(exp_avg, denom, value=-step_size)
+    }
+}
+
+extern "C" int hmvae_adam_step(const hmvae_adam_tensor* table_dev, int32_t n_tensors, int64_t max_numel,
+                               const float* lr_dev, const int32_t* step_dev, float beta1, float beta2, float eps,
+                               float weight_decay, hmvae_stream_t stream) {
+    if (!table_dev || !lr_dev || !step_dev || n_tensors <= 0 || max_numel <= 0) return HMVAE_ERR_ARG;
+    long long nb = (max_numel + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    dim3 grid((unsigned)nb, (unsigned)n_tensors);
+    hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, (hipStream_t)stream, table_dev, lr_dev, step_dev, beta1, beta2, eps,
+                       weight_decay);
+    return LAUNCH_OK();
+}
+
+extern "C" int hmvae_version(void) { return 1; }
+
+extern "C" const char* hmvae_error_string(int code) {
+    switch (code) {
+        case HMVAE_OK: return "ok";
+        case HMVAE_ERR_ARG: return "invalid argument (null pointer, bad size or alignment)";
+        case HMVAE_ERR_LAUNCH: return "HIP kernel launch failed";
+        case HMVAE_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown error";
+    }
+}

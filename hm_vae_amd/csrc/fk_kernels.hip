@@ -1,0 +1,554 @@
+// fk_kernels.hip — rotation-6D lift, forward kinematics and the fused decode tail (gfx950).
+//
+// Reference code replaced (paths relative to the reference root):
+//   my_tools.py:6-39        normalize_vector / cross_product / rotation_matrix_from_ortho6d
+//   fk_layer.py:47-93       ForwardKinematicsLayer (4x4 homogeneous chain, 23 gather+bmm+copy_ steps)
+//   seq_two_hier_sa_vae.py:436-474 _decode tail, :395-397/:430-434 the three MSE losses (+ autograd)
+//
+// One thread owns one frame.  The SMPL-24 kinematic tree is compile-time: the traversal is a template
+// recursion (depth-first), so the global rotation of a joint lives in registers only while its subtree
+// is being visited; nothing 4x4 or (N,24,4,4) is ever materialised.  The backward pass is fused in the
+// same traversal: a node returns S = sum of dP over its subtree and H·R^T, the gradient it hands to its
+// parent's global rotation ("FK backward recursion").
+//   p_j = p_par + G_par·off_j,  G_j = G_par·R_j
+//   H_j = sum_{c child of j} ( H_c·R_c^T + S_c ⊗ off_c ),   dR_j = dR_j(direct) + G_par^T·H_j
+#include <hip/hip_runtime.h>
+#include "hmvae.h"
+
+namespace {
+
+constexpr int NJ = 24;
+// utils/data/joint24_parents.json
+__host__ __device__ constexpr int smpl_parent(int j) {
+    constexpr int P[NJ] = {-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21};
+    return P[j];
+}
+__host__ __device__ constexpr bool has_children(int j) {
+    for (int c = 0; c < NJ; ++c)
+        if (smpl_parent(c) == j) return true;
+    return false;
+}
+
+struct V3 {
+    float x, y, z;
+};
+struct M3 {
+    float a[9];  // row-major
+};
+
+__device__ __forceinline__ V3 operator+(V3 u, V3 v) { return {u.x + v.x, u.y + v.y, u.z + v.z}; }
+__device__ __forceinline__ V3 mulv(const M3& A, V3 v) {
+    return {A.a[0] * v.x + A.a[1] * v.y + A.a[2] * v.z, A.a[3] * v.x + A.a[4] * v.y + A.a[5] * v.z,
+            A.a[6] * v.x + A.a[7] * v.y + A.a[8] * v.z};
+}
+__device__ __forceinline__ M3 mul(const M3& A, const M3& B) {
+    M3 C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C.a[i * 3 + j] = A.a[i * 3] * B.a[j] + A.a[i * 3 + 1] * B.a[3 + j] + A.a[i * 3 + 2] * B.a[6 + j];
+    return C;
+}
+// A^T * B
+__device__ __forceinline__ M3 mul_tn(const M3& A, const M3& B) {
+    M3 C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C.a[i * 3 + j] = A.a[i] * B.a[j] + A.a[3 + i] * B.a[3 + j] + A.a[6 + i] * B.a[6 + j];
+    return C;
+}
+// A * B^T
+__device__ __forceinline__ M3 mul_nt(const M3& A, const M3& B) {
+    M3 C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            C.a[i * 3 + j] = A.a[i * 3] * B.a[j * 3] + A.a[i * 3 + 1] * B.a[j * 3 + 1] + A.a[i * 3 + 2] * B.a[j * 3 + 2];
+    return C;
+}
+__device__ __forceinline__ void add_outer(M3& H, V3 s, V3 o) {
+    H.a[0] += s.x * o.x; H.a[1] += s.x * o.y; H.a[2] += s.x * o.z;
+    H.a[3] += s.y * o.x; H.a[4] += s.y * o.y; H.a[5] += s.y * o.z;
+    H.a[6] += s.z * o.x; H.a[7] += s.z * o.y; H.a[8] += s.z * o.z;
+}
+__device__ __forceinline__ void add_m(M3& A, const M3& B) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A.a[i] += B.a[i];
+}
+
+// my_tools.py:10-17 — products rounded separately (no fma), like the reference's tensor ops
+__device__ __forceinline__ V3 cross_exact(V3 u, V3 v) {
+#pragma clang fp contract(off)
+    V3 r;
+    r.x = u.y * v.z - u.z * v.y;
+    r.y = u.z * v.x - u.x * v.z;
+    r.z = u.x * v.y - u.y * v.x;
+    return r;
+}
+__device__ __forceinline__ float norm_exact(V3 v) {
+#pragma clang fp contract(off)
+    return sqrtf((v.x * v.x + v.y * v.y) + v.z * v.z);
+}
+
+constexpr float kEps = 1e-6f;  // F.normalize(eps=1e-6), my_tools.py:8
+
+// my_tools.py:19-39: x = n(a), z = n(x × b), y = z × x, columns of R are (x, y, z)
+__device__ __forceinline__ void lift6d(const float* in, M3& R) {
+    const V3 a = {in[0], in[1], in[2]}, b = {in[3], in[4], in[5]};
+    const float na = fmaxf(norm_exact(a), kEps);
+    const V3 x = {a.x / na, a.y / na, a.z / na};
+    const V3 zr = cross_exact(x, b);
+    const float nz = fmaxf(norm_exact(zr), kEps);
+    const V3 z = {zr.x / nz, zr.y / nz, zr.z / nz};
+    const V3 y = cross_exact(z, x);
+    R.a[0] = x.x; R.a[1] = y.x; R.a[2] = z.x;
+    R.a[3] = x.y; R.a[4] = y.y; R.a[5] = z.y;
+    R.a[6] = x.z; R.a[7] = y.z; R.a[8] = z.z;
+}
+
+__device__ __forceinline__ V3 cross_f(V3 u, V3 v) {
+    return {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+}
+__device__ __forceinline__ float dot_f(V3 u, V3 v) { return u.x * v.x + u.y * v.y + u.z * v.z; }
+
+// backward of lift6d: given the 6D input and dL/dR, return dL/d(in)
+__device__ __forceinline__ void lift6d_bwd(const float* in, const M3& dR, float* din) {
+    const V3 a = {in[0], in[1], in[2]}, b = {in[3], in[4], in[5]};
+    const float na_raw = norm_exact(a);
+    const float na = fmaxf(na_raw, kEps);
+    const V3 x = {a.x / na, a.y / na, a.z / na};
+    const V3 zr = cross_exact(x, b);
+    const float nz_raw = norm_exact(zr);
+    const float nz = fmaxf(nz_raw, kEps);
+    const V3 z = {zr.x / nz, zr.y / nz, zr.z / nz};
+    V3 dx = {dR.a[0], dR.a[3], dR.a[6]};
+    const V3 dy = {dR.a[1], dR.a[4], dR.a[7]};
+    V3 dz = {dR.a[2], dR.a[5], dR.a[8]};
+    // y = z × x
+    dz = dz + cross_f(x, dy);
+    dx = dx + cross_f(dy, z);
+    // z = zr / max(|zr|, eps)
+    V3 dzr;
+    if (nz_raw >= kEps) {
+        const float s = dot_f(z, dz);
+        dzr = {(dz.x - z.x * s) / nz, (dz.y - z.y * s) / nz, (dz.z - z.z * s) / nz};
+    } else {
+        dzr = {dz.x / kEps, dz.y / kEps, dz.z / kEps};
+    }
+    // zr = x × b
+    dx = dx + cross_f(b, dzr);
+    const V3 db = cross_f(dzr, x);
+    // x = a / max(|a|, eps)
+    V3 da;
+    if (na_raw >= kEps) {
+        const float s = dot_f(x, dx);
+        da = {(dx.x - x.x * s) / na, (dx.y - x.y * s) / na, (dx.z - x.z * s) / na};
+    } else {
+        da = {dx.x / kEps, dx.y / kEps, dx.z / kEps};
+    }
+    din[0] = da.x; din[1] = da.y; din[2] = da.z;
+    din[3] = db.x; din[4] = db.y; din[5] = db.z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward traversal
+// IO policy: void rot(int j, M3&), V3 off(int j), void put_R(int j, const M3&), void put_P(int j, V3)
+// ------------------------------------------------------------------------------------------------
+template <int J, class IO>
+__device__ __forceinline__ void fk_fwd_node(const M3& Gp, V3 Pp, IO& io);
+
+template <int J, int C, class IO>
+__device__ __forceinline__ void fk_fwd_children(const M3& G, V3 P, IO& io) {
+    if constexpr (C < NJ) {
+        if constexpr (smpl_parent(C) == J) fk_fwd_node<C>(G, P, io);
+        fk_fwd_children<J, C + 1>(G, P, io);
+    }
+}
+
+template <int J, class IO>
+__device__ __forceinline__ void fk_fwd_node(const M3& Gp, V3 Pp, IO& io) {
+    M3 R;
+    io.rot(J, R);
+    io.put_R(J, R);
+    const V3 P = Pp + mulv(Gp, io.off(J));
+    io.put_P(J, P);
+    if constexpr (has_children(J)) {
+        const M3 G = mul(Gp, R);
+        fk_fwd_children<J, J + 1>(G, P, io);
+    }
+}
+
+template <class IO>
+__device__ __forceinline__ void fk_fwd_root(IO& io) {
+    M3 R;
+    io.rot(0, R);
+    io.put_R(0, R);
+    const V3 P = io.off(0);            // fk_layer.py:69 — the root keeps its own offset as position
+    io.put_P(0, P);
+    fk_fwd_children<0, 1>(R, P, io);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused forward + backward traversal
+// IO policy adds: V3 grad_P(int j, V3 P), void grad_R(int j, const M3& R, M3& dR), void emit(int j, const M3& dR)
+// ------------------------------------------------------------------------------------------------
+template <int J, class IO>
+__device__ __forceinline__ void fk_bwd_node(const M3& Gp, V3 Pp, IO& io, V3& S_out, M3& HRt_out);
+
+template <int J, int C, class IO>
+__device__ __forceinline__ void fk_bwd_children(const M3& G, V3 P, IO& io, V3& S, M3& H) {
+    if constexpr (C < NJ) {
+        if constexpr (smpl_parent(C) == J) {
+            V3 Sc;
+            M3 Hc;
+            fk_bwd_node<C>(G, P, io, Sc, Hc);
+            S = S + Sc;
+            add_m(H, Hc);
+            add_outer(H, Sc, io.off(C));
+        }
+        fk_bwd_children<J, C + 1>(G, P, io, S, H);
+    }
+}
+
+template <int J, class IO>
+__device__ __forceinline__ void fk_bwd_node(const M3& Gp, V3 Pp, IO& io, V3& S_out, M3& HRt_out) {
+    M3 R;
+    io.rot(J, R);
+    const V3 P = Pp + mulv(Gp, io.off(J));
+    V3 S = io.grad_P(J, P);
+    M3 dR;
+    if constexpr (has_children(J)) {
+        M3 H;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) H.a[i] = 0.f;
+        {
+            const M3 G = mul(Gp, R);
+            fk_bwd_children<J, J + 1>(G, P, io, S, H);
+        }
+        io.rot(J, R);                  // re-read instead of keeping 9 registers live across the subtree
+        io.grad_R(J, R, dR);
+        add_m(dR, mul_tn(Gp, H));
+        HRt_out = mul_nt(H, R);
+    } else {
+        io.grad_R(J, R, dR);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) HRt_out.a[i] = 0.f;
+    }
+    io.emit(J, dR);
+    S_out = S;
+}
+
+template <class IO>
+__device__ __forceinline__ void fk_bwd_root(IO& io) {
+    M3 R;
+    io.rot(0, R);
+    const V3 P = io.off(0);
+    V3 S = io.grad_P(0, P);            // position of the root is a constant: S is only a by-product
+    M3 H;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) H.a[i] = 0.f;
+    fk_bwd_children<0, 1>(R, P, io, S, H);
+    io.rot(0, R);
+    M3 dR;
+    io.grad_R(0, R, dR);
+    add_m(dR, H);
+    io.emit(0, dR);
+}
+
+// ------------------------------------------------------------------------------------------------
+// AoS policies (reference layout: frame-major (N, J, 6|9|3))
+// ------------------------------------------------------------------------------------------------
+template <int RD>
+struct AosFwd {
+    const float* rin;      // this frame: J*RD floats
+    const float* offs;     // J*3
+    float* R_out;          // or nullptr
+    float* P_out;          // or nullptr
+    __device__ __forceinline__ void rot(int j, M3& R) const {
+        if constexpr (RD == 6) {
+            float in[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) in[k] = rin[j * 6 + k];
+            lift6d(in, R);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R.a[k] = rin[j * 9 + k];
+        }
+    }
+    __device__ __forceinline__ V3 off(int j) const { return {offs[j * 3], offs[j * 3 + 1], offs[j * 3 + 2]}; }
+    __device__ __forceinline__ void put_R(int j, const M3& R) const {
+        if (R_out) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R_out[j * 9 + k] = R.a[k];
+        }
+    }
+    __device__ __forceinline__ void put_P(int j, V3 P) const {
+        if (P_out) {
+            P_out[j * 3] = P.x;
+            P_out[j * 3 + 1] = P.y;
+            P_out[j * 3 + 2] = P.z;
+        }
+    }
+};
+
+template <int RD>
+__global__ __launch_bounds__(256) void fk_fwd_aos_kernel(const float* __restrict__ rot, const float* __restrict__ offs,
+                                                         long long off_stride, long long n, float* __restrict__ R_out,
+                                                         float* __restrict__ P_out) {
+    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n) return;
+    AosFwd<RD> io{rot + f * (NJ * RD), offs + f * off_stride, R_out ? R_out + f * (NJ * 9) : nullptr,
+                  P_out ? P_out + f * (NJ * 3) : nullptr};
+    fk_fwd_root(io);
+}
+
+template <int RD>
+struct AosBwd {
+    const float* rin;
+    const float* offs;
+    const float* dR_up;    // J*9 or nullptr
+    const float* dP_up;    // J*3 or nullptr
+    float* d_rot;          // J*RD
+    __device__ __forceinline__ void rot_in(int j, float* in) const {
+#pragma unroll
+        for (int k = 0; k < RD; ++k) in[k] = rin[j * RD + k];
+    }
+    __device__ __forceinline__ void rot(int j, M3& R) const {
+        float in[RD];
+        rot_in(j, in);
+        if constexpr (RD == 6) lift6d(in, R);
+        else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R.a[k] = in[k];
+        }
+    }
+    __device__ __forceinline__ V3 off(int j) const { return {offs[j * 3], offs[j * 3 + 1], offs[j * 3 + 2]}; }
+    __device__ __forceinline__ V3 grad_P(int j, V3) const {
+        if (dP_up) return {dP_up[j * 3], dP_up[j * 3 + 1], dP_up[j * 3 + 2]};
+        return {0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void grad_R(int j, const M3&, M3& dR) const {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dR.a[k] = dR_up ? dR_up[j * 9 + k] : 0.f;
+    }
+    __device__ __forceinline__ void emit(int j, const M3& dR) const {
+        if constexpr (RD == 6) {
+            float in[6], din[6];
+            rot_in(j, in);
+            lift6d_bwd(in, dR, din);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d_rot[j * 6 + k] = din[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) d_rot[j * 9 + k] = dR.a[k];
+        }
+    }
+};
+
+template <int RD>
+__global__ __launch_bounds__(256) void fk_bwd_aos_kernel(const float* __restrict__ rot, const float* __restrict__ offs,
+                                                         long long off_stride, long long n,
+                                                         const float* __restrict__ dR_up, const float* __restrict__ dP_up,
+                                                         float* __restrict__ d_rot) {
+    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n) return;
+    AosBwd<RD> io{rot + f * (NJ * RD), offs + f * off_stride, dR_up ? dR_up + f * (NJ * 9) : nullptr,
+                  dP_up ? dP_up + f * (NJ * 3) : nullptr, d_rot + f * (NJ * RD)};
+    fk_bwd_root(io);
+}
+
+bool is_smpl24(const int32_t* parents, int n_joints) {
+    if (!parents || n_joints != NJ) return false;
+    for (int j = 0; j < NJ; ++j)
+        if (parents[j] != smpl_parent(j)) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int hmvae_fk_fwd(const float* rot, int32_t rot_dim, const float* offsets, int64_t offset_stride,
+                            const int32_t* parents_host, int32_t n_joints, int64_t n_frames, float* R_out,
+                            float* pos_out, hmvae_stream_t stream) {
+    if (!rot || !offsets || n_frames <= 0 || (rot_dim != 6 && rot_dim != 9)) return HMVAE_ERR_ARG;
+    if (offset_stride != 0 && offset_stride != NJ * 3) return HMVAE_ERR_ARG;
+    if (!is_smpl24(parents_host, n_joints)) return HMVAE_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)((n_frames + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (rot_dim == 6)
+        hipLaunchKernelGGL(fk_fwd_aos_kernel<6>, grid, block, 0, s, rot, offsets, (long long)offset_stride,
+                           (long long)n_frames, R_out, pos_out);
+    else
+        hipLaunchKernelGGL(fk_fwd_aos_kernel<9>, grid, block, 0, s, rot, offsets, (long long)offset_stride,
+                           (long long)n_frames, R_out, pos_out);
+    return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+}
+
+extern "C" int hmvae_fk_bwd(const float* rot, int32_t rot_dim, const float* offsets, int64_t offset_stride,
+                            const int32_t* parents_host, int32_t n_joints, int64_t n_frames, const float* dR,
+                            const float* dpos, float* d_rot, hmvae_stream_t stream) {
+    if (!rot || !offsets || !d_rot || n_frames <= 0 || (rot_dim != 6 && rot_dim != 9)) return HMVAE_ERR_ARG;
+    if (offset_stride != 0 && offset_stride != NJ * 3) return HMVAE_ERR_ARG;
+    if (!is_smpl24(parents_host, n_joints)) return HMVAE_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)((n_frames + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (rot_dim == 6)
+        hipLaunchKernelGGL(fk_bwd_aos_kernel<6>, grid, block, 0, s, rot, offsets, (long long)offset_stride,
+                           (long long)n_frames, dR, dpos, d_rot);
+    else
+        hipLaunchKernelGGL(fk_bwd_aos_kernel<9>, grid, block, 0, s, rot, offsets, (long long)offset_stride,
+                           (long long)n_frames, dR, dpos, d_rot);
+    return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode tail on SoA decoder output: rows (j*6+c), position t, batch column b -> ((j*6+c)*T + t)*bp + b
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct TailLoss {
+    const float* x;        // dec_out + t*bp + b
+    const float* g6;       // gt 6d, same addressing
+    const float* gR;       // gt R rows (j*9+k)
+    const float* gP;       // gt pos rows (j*3+k)
+    const float* offs;
+    float* dx;             // d dec_out
+    size_t rs;             // row stride between consecutive channels = T*bp
+    float s6, sR, sP;      // sums of squared errors
+    float c6, cR, cP;      // 2*weight/numel
+    __device__ __forceinline__ void rot_in(int j, float* in) const {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) in[k] = x[(size_t)(j * 6 + k) * rs];
+    }
+    __device__ __forceinline__ void rot(int j, M3& R) const {
+        float in[6];
+        rot_in(j, in);
+        lift6d(in, R);
+    }
+    __device__ __forceinline__ V3 off(int j) const { return {offs[j * 3], offs[j * 3 + 1], offs[j * 3 + 2]}; }
+    __device__ __forceinline__ V3 grad_P(int j, V3 P) {
+        const float ex = P.x - gP[(size_t)(j * 3) * rs], ey = P.y - gP[(size_t)(j * 3 + 1) * rs],
+                    ez = P.z - gP[(size_t)(j * 3 + 2) * rs];
+        sP += ex * ex + ey * ey + ez * ez;
+        return {cP * ex, cP * ey, cP * ez};
+    }
+    __device__ __forceinline__ void grad_R(int j, const M3& R, M3& dR) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float e = R.a[k] - gR[(size_t)(j * 9 + k) * rs];
+            sR += e * e;
+            dR.a[k] = cR * e;
+        }
+    }
+    __device__ __forceinline__ void emit(int j, const M3& dR) {
+        float in[6], din[6];
+        rot_in(j, in);
+        lift6d_bwd(in, dR, din);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float e = in[k] - g6[(size_t)(j * 6 + k) * rs];
+            s6 += e * e;
+            dx[(size_t)(j * 6 + k) * rs] = din[k] + c6 * e;
+        }
+    }
+};
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void decode_tail_loss_kernel(const float* __restrict__ dec, const float* __restrict__ g6,
+                                                              const float* __restrict__ gR, const float* __restrict__ gP,
+                                                              const float* __restrict__ offs, int T, int B, int bp,
+                                                              float c6, float cR, float cP, float* __restrict__ ddec,
+                                                              float* __restrict__ partial) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int t = blockIdx.y;
+    const size_t rs = (size_t)T * bp;
+    const size_t o = (size_t)t * bp + b;
+    float s6 = 0.f, sR = 0.f, sP = 0.f;
+    if (b < B) {
+        TailLoss io{dec + o, g6 + o, gR + o, gP + o, offs, ddec + o, rs, 0.f, 0.f, 0.f, c6, cR, cP};
+        fk_bwd_root(io);
+        s6 = io.s6;
+        sR = io.sR;
+        sP = io.sP;
+    } else if (b < bp) {
+        for (int r = 0; r < NJ * 6; ++r) ddec[o + (size_t)r * rs] = 0.f;   // padded batch columns carry zero gradient
+    }
+    s6 = wave_sum_f(s6);
+    sR = wave_sum_f(sR);
+    sP = wave_sum_f(sP);
+    if (threadIdx.x == 0) {
+        float* p = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3;
+        p[0] = s6;
+        p[1] = sR;
+        p[2] = sP;
+    }
+}
+
+struct TailFwd {
+    const float* x;
+    const float* offs;
+    size_t rs;
+    float* c6;   // this frame: 144
+    float* R;    // 216
+    float* P;    // 72
+    __device__ __forceinline__ void rot(int j, M3& Rm) const {
+        float in[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            in[k] = x[(size_t)(j * 6 + k) * rs];
+            c6[j * 6 + k] = in[k];
+        }
+        lift6d(in, Rm);
+    }
+    __device__ __forceinline__ V3 off(int j) const { return {offs[j * 3], offs[j * 3 + 1], offs[j * 3 + 2]}; }
+    __device__ __forceinline__ void put_R(int j, const M3& Rm) const {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[j * 9 + k] = Rm.a[k];
+    }
+    __device__ __forceinline__ void put_P(int j, V3 p) const {
+        P[j * 3] = p.x;
+        P[j * 3 + 1] = p.y;
+        P[j * 3 + 2] = p.z;
+    }
+};
+
+__global__ __launch_bounds__(64) void decode_tail_fwd_kernel(const float* __restrict__ dec, const float* __restrict__ offs,
+                                                             int T, int B, int bp, float* __restrict__ c6,
+                                                             float* __restrict__ R, float* __restrict__ P) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int t = blockIdx.y;
+    if (b >= B) return;
+    const size_t f = (size_t)b * T + t;
+    TailFwd io{dec + (size_t)t * bp + b, offs, (size_t)T * bp, c6 + f * (NJ * 6), R + f * (NJ * 9), P + f * (NJ * 3)};
+    fk_fwd_root(io);
+}
+
+}  // namespace
+
+extern "C" int hmvae_decode_tail_loss(const float* dec_out, const float* gt6d, const float* gtR, const float* gtP,
+                                      const float* offsets, int32_t T, int32_t B, int32_t bp, float scale_6d,
+                                      float scale_rot, float scale_pos, float* d_dec_out, float* partial,
+                                      int32_t* n_blocks_out, hmvae_stream_t stream) {
+    if (!dec_out || !gt6d || !gtR || !gtP || !offsets || !d_dec_out || !partial) return HMVAE_ERR_ARG;
+    if (T <= 0 || T > 65535 || B <= 0 || bp < B || (bp & 63)) return HMVAE_ERR_ARG;
+    dim3 grid(bp / 64, T), block(64);
+    if (n_blocks_out) *n_blocks_out = (int32_t)(grid.x * grid.y);
+    hipLaunchKernelGGL(decode_tail_loss_kernel, grid, block, 0, (hipStream_t)stream, dec_out, gt6d, gtR, gtP, offsets, T, B,
+                       bp, 2.f * scale_6d, 2.f * scale_rot, 2.f * scale_pos, d_dec_out, partial);
+    return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+}
+
+extern "C" int hmvae_decode_tail_fwd(const float* dec_out, const float* offsets, int32_t T, int32_t B, int32_t bp,
+                                     float* c6, float* R, float* pos, hmvae_stream_t stream) {
+    if (!dec_out || !offsets || !c6 || !R || !pos) return HMVAE_ERR_ARG;
+    if (T <= 0 || T > 65535 || B <= 0 || bp < B || (bp & 63)) return HMVAE_ERR_ARG;
+    dim3 grid(bp / 64, T), block(64);
+    hipLaunchKernelGGL(decode_tail_fwd_kernel, grid, block, 0, (hipStream_t)stream, dec_out, offsets, T, B, bp, c6, R, pos);
+    return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+}

@@ -1,0 +1,358 @@
+// gemm_kernels.hip — fp32-MFMA gather-GEMM, weight-gradient GEMM, weight packing (gfx950).
+//
+// Replaces, for the hm-vae hot path (reference paths):
+//   skeleton.py:95-105   SkeletonConv.forward  (weight*mask, F.pad reflect, F.conv1d)  and its autograd
+//   seq_two_hier_sa_vae.py:162,267  nn.Linear latent heads and their autograd
+//
+// Data layout: activations are [row][Bp] with batch innermost (Bp % 64 == 0), row = channel*T + t.
+// MFMA: v_mfma_f32_16x16x4_f32 — A: lane l holds A[m=l&15][k=l>>4]; B: lane l holds B[k=l>>4][n=l&15];
+// D: lane l, reg r holds D[row=(l>>4)*4+r][col=l&15]  (cdna_hip_programming.md §3).
+//
+// gather-GEMM work split: one workgroup = one (row-group, output position, 64-column batch tile);
+// its 4 waves split the reduction over 4-channel steps and are summed through LDS.  The 64 columns of a
+// tile are permuted (MFMA tile j, column n  <->  batch column 4n+j) so that one 16-byte load per lane
+// feeds all four 16-column MFMA tiles and the epilogue stores 16 bytes per lane.
+#include <hip/hip_runtime.h>
+#include "hmvae.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int MT>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(hmvae_gemm_desc d) {
+    __shared__ __attribute__((aligned(16))) float red[4 * MT * 16 * 64];
+    const int n_ct = d.bp >> 6;
+    int bid = blockIdx.x;
+    const int g = bid % d.n_groups;
+    bid /= d.n_groups;
+    const int ct = bid % n_ct;
+    const int p = bid / n_ct;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int kk = lane >> 4;
+    const int n = lane & 15;
+
+    const int nc4 = d.g_nc4[g];
+    const int choff = d.g_choff[g];
+    const int poff = d.p_off[p];
+    const int plen = d.p_len[p];
+    const float* __restrict__ wg = d.wp + d.g_woff[g] + lane;
+    const float* __restrict__ srcc = d.src + (ct << 6) + (n << 2);
+    const int* __restrict__ pairs = d.pairs + poff;
+    const int bp = d.bp;
+    const int src_ts = d.src_ts;
+    const int kt = d.kt;
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (plen > 0 && wave < nc4) {
+        int c4 = wave;
+        int i = 0;
+        int rowbase = d.chan_rows[choff + c4 * 4 + kk];
+        int rowbase_nx = (c4 + 4 < nc4) ? d.chan_rows[choff + (c4 + 4) * 4 + kk] : 0;
+        float a_cur[MT];
+        f32x4 b_cur;
+        {
+            const int pr = pairs[0];
+            const int q = pr & 0xffff, tap = pr >> 16;
+            const float* wc = wg + (size_t)(c4 * kt + tap) * (MT * 64);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a_cur[mt] = wc[mt * 64];
+            b_cur = *(const f32x4*)(srcc + (size_t)(rowbase + q * src_ts) * bp);
+        }
+        bool more = true;
+        while (more) {
+            int ni = i + 1, nc = c4;
+            int rb = rowbase;
+            if (ni == plen) {
+                ni = 0;
+                nc += 4;
+                rb = rowbase_nx;
+            }
+            const bool nvalid = nc < nc4;
+            float a_nx[MT];
+            f32x4 b_nx;
+            if (nvalid) {
+                const int pr = pairs[ni];
+                const int q = pr & 0xffff, tap = pr >> 16;
+                const float* wc = wg + (size_t)(nc * kt + tap) * (MT * 64);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a_nx[mt] = wc[mt * 64];
+                b_nx = *(const f32x4*)(srcc + (size_t)(rb + q * src_ts) * bp);
+                if (nc != c4) {
+                    rowbase = rb;
+                    rowbase_nx = (nc + 4 < nc4) ? d.chan_rows[choff + (nc + 4) * 4 + kk] : 0;
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mt][j] = MFMA16(a_cur[mt], b_cur[j], acc[mt][j]);
+            }
+            if (nvalid) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nx[mt];
+                b_cur = b_nx;
+            }
+            c4 = nc;
+            i = ni;
+            more = nvalid;
+        }
+    }
+
+    // cross-wave reduction through LDS; acc[mt][j][r] is row mt*16+kk*4+r, batch column 4n+j
+    float* mine = red + wave * (MT * 16 * 64);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+            *(f32x4*)(mine + (mt * 16 + kk * 4 + r) * 64 + (n << 2)) = v;
+        }
+    }
+    __syncthreads();
+    const int rl = threadIdx.x >> 4;   // 0..15
+    const int cq = threadIdx.x & 15;   // column quad
+#pragma unroll
+    for (int ps = 0; ps < MT; ++ps) {
+        const int row = ps * 16 + rl;
+        const int drow = d.dst_rows[g * (MT * 16) + row];
+        if (drow < 0) continue;
+        f32x4 s = *(const f32x4*)(red + row * 64 + (cq << 2));
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            f32x4 t = *(const f32x4*)(red + w * (MT * 16 * 64) + row * 64 + (cq << 2));
+            s += t;
+        }
+        if (d.bias) {
+            const int bi = d.bias_idx[g * (MT * 16) + row];
+            const float bv = bi >= 0 ? d.bias[bi] : 0.f;
+            s += (f32x4){bv, bv, bv, bv};
+        }
+        if (d.flags & HMVAE_FLAG_LEAKY) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = s[e] > 0.f ? s[e] : s[e] * d.slope;
+        }
+        float* dp = d.dst + (size_t)(drow + p * d.dst_ts) * bp + (ct << 6) + (cq << 2);
+        if (d.flags & HMVAE_FLAG_ACCUM) {
+            f32x4 o = *(const f32x4*)dp;
+            s += o;
+        }
+        *(f32x4*)dp = s;
+    }
+}
+
+extern "C" int hmvae_gather_gemm(const hmvae_gemm_desc* desc, hmvae_stream_t stream) {
+    if (!desc || !desc->src || !desc->dst || !desc->wp || (desc->bias && !desc->bias_idx)) return HMVAE_ERR_ARG;
+    if (desc->bp <= 0 || (desc->bp & 63) || desc->n_groups <= 0 || desc->n_pos <= 0 || desc->kt <= 0) return HMVAE_ERR_ARG;
+    const long long nblk = (long long)desc->n_groups * desc->n_pos * (desc->bp >> 6);
+    if (nblk > 0x7fffffffLL) return HMVAE_ERR_ARG;
+    dim3 grid((unsigned)nblk), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (desc->mt) {
+        case 1: hipLaunchKernelGGL(gather_gemm_kernel<1>, grid, block, 0, s, *desc); break;
+        case 2: hipLaunchKernelGGL(gather_gemm_kernel<2>, grid, block, 0, s, *desc); break;
+        case 3: hipLaunchKernelGGL(gather_gemm_kernel<3>, grid, block, 0, s, *desc); break;
+        case 4: hipLaunchKernelGGL(gather_gemm_kernel<4>, grid, block, 0, s, *desc); break;
+        default: return HMVAE_ERR_UNSUPPORTED;
+    }
+    return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: rows = group rows (dz), columns = (listed channel, tap), reduction over (t, batch).
+// K permutation: MFMA k-step j of a 16-batch block uses batch elements {4*kk + j}, so each lane feeds
+// four k-steps from one 16-byte load on both operands.
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
+    __shared__ __attribute__((aligned(16))) float red[4 * MT * 16 * 64];
+    const int tile = blockIdx.x % d.n_tiles;
+    const int sp = blockIdx.x / d.n_tiles;
+    const int g = d.tile_g[tile];
+    const int col0 = d.tile_col0[tile];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int kk = lane >> 4;
+    const int n = lane & 15;
+    const int bp = d.bp;
+    const int ncols = d.g_ncols[g];
+    const int choff = d.g_choff[g];
+
+    int dzrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int r = d.dz_rows[g * (MT * 16) + mt * 16 + n];
+        dzrow[mt] = r < 0 ? 0 : r;
+    }
+    int xrow[4], tap[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = col0 + nt * 16 + n;
+        if (col < ncols) {
+            const int c = col / d.kt;
+            tap[nt] = col - c * d.kt;
+            xrow[nt] = d.chan_rows[choff + c];
+        } else {
+            tap[nt] = 0;
+            xrow[nt] = d.chan_rows[choff];
+        }
+    }
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nb16 = bp >> 4;
+    const long long total = (long long)d.t_dst * nb16;
+    const int lo = (int)(total * sp / d.n_split);
+    const int hi = (int)(total * (sp + 1) / d.n_split);
+    const float* __restrict__ dzp = d.dz + (kk << 2);
+    const float* __restrict__ xp = d.x + (kk << 2);
+    for (int chunk = lo + wave; chunk < hi; chunk += 4) {
+        const int t = chunk / nb16;
+        const int b0 = (chunk - t * nb16) << 4;
+        f32x4 a[MT], b[4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(dzp + (size_t)(dzrow[mt] + t * d.dz_ts) * bp + b0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            int u = t * d.stride + tap[nt] - d.pad;
+            bool ok = true;
+            if (d.pad_mode == HMVAE_PAD_REFLECT) {
+                if (u < 0) u = -u;
+                if (u >= d.t_src) u = 2 * (d.t_src - 1) - u;
+            } else {
+                ok = (u >= 0) && (u < d.t_src);
+                if (!ok) u = 0;
+            }
+            f32x4 v = *(const f32x4*)(xp + (size_t)(xrow[nt] + u * d.x_ts) * bp + b0);
+            b[nt] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(a[mt][j], b[nt][j], acc[mt][nt]);
+    }
+    // acc[mt][nt][r] is row mt*16 + kk*4 + r, column nt*16 + n
+    float* mine = red + wave * (MT * 16 * 64);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(mt * 16 + kk * 4 + r) * 64 + nt * 16 + n] = acc[mt][nt][r];
+    __syncthreads();
+    const int rl = threadIdx.x >> 4;
+    const int cq = threadIdx.x & 15;
+    float* out = d.slab + ((size_t)sp * d.n_tiles + tile) * (MT * 16 * 64);
+#pragma unroll
+    for (int ps = 0; ps < MT; ++ps) {
+        const int row = ps * 16 + rl;
+        f32x4 s = *(const f32x4*)(red + row * 64 + (cq << 2));
+#pragma unroll
+        for (int w = 1; w < 4; ++w) s += *(const f32x4*)(red + w * (MT * 16 * 64) + row * 64 + (cq << 2));
+        *(f32x4*)(out + row * 64 + (cq << 2)) = s;
+    }
+}
+
+extern "C" int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream) {
+    if (!desc || !desc->dz || !desc->x || !desc->slab) return HMVAE_ERR_ARG;
+    if (desc->bp <= 0 || (desc->bp & 63) || desc->n_tiles <= 0 || desc->n_split <= 0 || desc->kt <= 0) return HMVAE_ERR_ARG;
+    if (desc->pad_mode == HMVAE_PAD_REFLECT && desc->pad >= desc->t_src && desc->pad > 0) return HMVAE_ERR_ARG;
+    const long long nblk = (long long)desc->n_tiles * desc->n_split;
+    if (nblk > 0x7fffffffLL) return HMVAE_ERR_ARG;
+    dim3 grid((unsigned)nblk), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (desc->mt) {
+        case 1: hipLaunchKernelGGL(wgrad_kernel<1>, grid, block, 0, s, *desc); break;
+        case 2: hipLaunchKernelGGL(wgrad_kernel<2>, grid, block, 0, s, *desc); break;
+        case 3: hipLaunchKernelGGL(wgrad_kernel<3>, grid, block, 0, s, *desc); break;
+        case 4: hipLaunchKernelGGL(wgrad_kernel<4>, grid, block, 0, s, *desc); break;
+        default: return HMVAE_ERR_UNSUPPORTED;
+    }
+    return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+}
+
+__global__ __launch_bounds__(256) void wreduce_kernel(hmvae_wreduce_desc d) {
+    const int rows = d.mt * 16;
+    const long long per_tile = (long long)rows * 64;
+    const long long total = per_tile * d.n_tiles;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int tile = (int)(idx / per_tile);
+        const int rem = (int)(idx - (long long)tile * per_tile);
+        const int row = rem >> 6, col = rem & 63;
+        const int g = d.tile_g[tile];
+        const int gc = d.tile_col0[tile] + col;
+        if (gc >= d.g_ncols[g]) continue;
+        const int rid = d.row_id[g * rows + row];
+        if (rid < 0) continue;
+        const int c = gc / d.kt;
+        const int tap = gc - c * d.kt;
+        const int cid = d.chan_id[d.g_choff[g] + c];
+        if (cid < 0) continue;
+        if (!d.pair_ok[d.g_okoff[g] + row * (d.g_nc4[g] * 4) + c]) continue;
+        float s = 0.f;
+        for (int sp = 0; sp < d.n_split; ++sp) s += d.slab[((size_t)sp * d.n_tiles + tile) * per_tile + rem];
+        float* o = d.dense + (size_t)rid * d.row_stride + (size_t)cid * d.chan_stride + tap;
+        if (d.accumulate) s += *o;
+        *o = s;
+    }
+}
+
+extern "C" int hmvae_wgrad_reduce(const hmvae_wreduce_desc* desc, hmvae_stream_t stream) {
+    if (!desc || !desc->slab || !desc->dense || !desc->pair_ok || desc->n_tiles <= 0) return HMVAE_ERR_ARG;
+    const long long total = (long long)desc->n_tiles * desc->mt * 16 * 64;
+    long long nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *desc);
+    return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ dense, float* __restrict__ packed,
+                                                   const int* __restrict__ g_nc4, const int* __restrict__ g_woff,
+                                                   const int* __restrict__ g_choff, const int* __restrict__ chan_id,
+                                                   const int* __restrict__ row_id, const int* __restrict__ g_okoff,
+                                                   const unsigned char* __restrict__ pair_ok, int mt, int kt, int row_stride,
+                                                   int chan_stride, int tap_stride, int tap_flip) {
+    const int g = blockIdx.y;
+    const int per_c4 = kt * mt * 64;
+    const int total = g_nc4[g] * per_c4;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int c4 = idx / per_c4;
+        int rem = idx - c4 * per_c4;
+        const int tap = rem / (mt * 64);
+        rem -= tap * (mt * 64);
+        const int m_t = rem >> 6;
+        const int l = rem & 63;
+        const int kk = l >> 4, m = l & 15;
+        const int rid = row_id[g * (mt * 16) + m_t * 16 + m];
+        const int cid = chan_id[g_choff[g] + c4 * 4 + kk];
+        float v = 0.f;
+        if (rid >= 0 && cid >= 0 && pair_ok[g_okoff[g] + (m_t * 16 + m) * (g_nc4[g] * 4) + c4 * 4 + kk]) {
+            const int td = tap_flip ? (kt - 1 - tap) : tap;
+            v = dense[(size_t)rid * row_stride + (size_t)cid * chan_stride + (size_t)td * tap_stride];
+        }
+        packed[g_woff[g] + idx] = v;
+    }
+}
+
+extern "C" int hmvae_pack_weights(const float* dense, float* packed, const int32_t* g_nc4, const int32_t* g_woff,
+                                  const int32_t* g_choff, const int32_t* chan_id, const int32_t* row_id,
+                                  const int32_t* g_okoff, const uint8_t* pair_ok, int32_t n_groups, int32_t mt,
+                                  int32_t kt, int32_t row_stride, int32_t chan_stride, int32_t tap_stride,
+                                  int32_t tap_flip, hmvae_stream_t stream) {
+    if (!dense || !packed || !g_okoff || !pair_ok || n_groups <= 0 || mt < 1 || mt > 4 || kt <= 0) return HMVAE_ERR_ARG;
+    dim3 grid(64, (unsigned)n_groups), block(256);
+    hipLaunchKernelGGL(pack_kernel, grid, block, 0, (hipStream_t)stream, dense, packed, g_nc4, g_woff, g_choff, chan_id,
+                       row_id, g_okoff, pair_ok, mt, kt, row_stride, chan_stride, tap_stride, tap_flip);
+    return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+}

@@ -1,0 +1,318 @@
+"""Device-side operator objects: thin Python over the C ABI (include/hmvae.h).
+
+`MaskedGemm` is the workhorse: one masked dense matrix W[row, chan, tap] (a SkeletonConv weight with its
+neighbour mask, or an nn.Linear weight with kt=1) and the three MFMA passes that touch it:
+forward (gather-GEMM), backward-data (gather-GEMM on the transposed groups) and backward-weight.
+All activations are SoA: float [rows][Bp], batch innermost, Bp = batch rounded up to 64.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import planner as P
+
+
+def pad_batch(b):
+    return (int(b) + 63) // 64 * 64
+
+
+def _dev(arr, device):
+    return torch.from_numpy(np.ascontiguousarray(arr)).to(device)
+
+
+class _Side:
+    """One gather-GEMM direction: groups + position pairs + row maps (all on the device)."""
+
+    def __init__(self, device, groups, pairs, chan_row_base, row_dst_base, bias_rows, src_ts, dst_ts, dense_strides):
+        self.g = groups
+        self.device = device
+        self.row_id = _dev(groups.row_id, device)
+        self.chan_id = _dev(groups.chan_id, device)
+        self.g_nc4 = _dev(groups.g_nc4, device)
+        self.g_woff = _dev(groups.g_woff, device)
+        self.g_choff = _dev(groups.g_choff, device)
+        self.g_okoff = _dev(groups.g_okoff, device)
+        self.pair_ok = _dev(groups.pair_ok, device)
+        ch = groups.chan_id
+        valid = ch >= 0
+        # dummy channels read a valid row (their packed weights are exactly zero)
+        fallback = chan_row_base[int(ch[valid][0])] if valid.any() else 0
+        cr = np.where(valid, chan_row_base[np.maximum(ch, 0)], fallback)
+        self.chan_rows = _dev(cr.astype(np.int32), device)
+        ri = groups.row_id
+        dr = np.where(ri >= 0, row_dst_base[np.maximum(ri, 0)], -1)
+        self.dst_rows = _dev(dr.astype(np.int32), device)
+        if bias_rows is None:
+            self.bias_idx = self.row_id
+        else:
+            self.bias_idx = _dev(np.where(ri >= 0, bias_rows[np.maximum(ri, 0)], -1).astype(np.int32), device)
+        p_off, p_len, flat = P.flatten_pairs(pairs)
+        self.n_pos = len(pairs)
+        self.p_off, self.p_len, self.pairs = _dev(p_off, device), _dev(p_len, device), _dev(flat, device)
+        self.src_ts, self.dst_ts = int(src_ts), int(dst_ts)
+        self.strides = tuple(int(s) for s in dense_strides)       # (row_stride, chan_stride, tap_stride)
+        self.wp = torch.zeros(max(groups.packed_size, 1), dtype=torch.float32, device=device)
+
+    def pack(self, dense):
+        lib = _lib.load()
+        g = self.g
+        rs, cs, ts = self.strides
+        _lib.check(lib.hmvae_pack_weights(_lib.ptr(dense), _lib.ptr(self.wp), _lib.ptr(self.g_nc4), _lib.ptr(self.g_woff),
+                                          _lib.ptr(self.g_choff), _lib.ptr(self.chan_id), _lib.ptr(self.row_id),
+                                          _lib.ptr(self.g_okoff), _lib.ptr(self.pair_ok), g.n_groups, g.mt, g.kt, rs, cs,
+                                          ts, 0, _lib.stream()), "pack_weights")
+
+    def run(self, src, dst, bp, bias=None, flags=0, slope=0.2):
+        lib = _lib.load()
+        g = self.g
+        d = _lib.GemmDesc(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(self.wp), _lib.ptr(bias), _lib.ptr(self.bias_idx),
+                          _lib.ptr(self.g_nc4), _lib.ptr(self.g_woff), _lib.ptr(self.g_choff), _lib.ptr(self.chan_rows),
+                          _lib.ptr(self.dst_rows), _lib.ptr(self.p_off), _lib.ptr(self.p_len), _lib.ptr(self.pairs),
+                          g.n_groups, g.mt, g.kt, self.n_pos, int(bp), self.src_ts, self.dst_ts, int(flags), float(slope))
+        _lib.check(lib.hmvae_gather_gemm(C.byref(d), _lib.stream()), "gather_gemm")
+
+
+class MaskedGemm:
+    """W[row, chan, tap] with a block mask; forward / backward-data / backward-weight on MFMA.
+
+    rows_f, chans_f : per block, dense row ids and the dense channel ids they read (forward grouping)
+    rows_b, chans_b : the transposed relation (rows = forward channels), or None when no data gradient is needed
+    pairs_f / pairs_b : per output position, [(source position, tap)]
+    x_row(chan) = x_base[chan] + q * x_ts           (input activation rows)
+    y_row(row)  = y_base[row]  + p * y_ts           (output activation rows)
+    """
+
+    def __init__(self, device, w_shape, rows_f, chans_f, rows_b, chans_b, pairs_f, pairs_b, x_base, y_base, x_ts, y_ts,
+                 conv_geom=None, bias_rows=None):
+        n_rows, n_chan, kt = w_shape
+        self.w_shape = tuple(int(v) for v in w_shape)
+        self.kt = int(kt)
+        self.device = device
+        x_base = np.asarray(x_base, dtype=np.int64)
+        y_base = np.asarray(y_base, dtype=np.int64)
+        gf = P.make_groups(rows_f, chans_f, kt)
+        self.fwd = _Side(device, gf, pairs_f, x_base, y_base, bias_rows, x_ts, y_ts, (n_chan * kt, kt, 1))
+        self.bwd = None
+        if rows_b is not None:
+            gb = P.make_groups(rows_b, chans_b, kt)
+            # transposed: "rows" are forward channels, "channels" are forward rows
+            self.bwd = _Side(device, gb, pairs_b, y_base, x_base, None, y_ts, x_ts, (kt, n_chan * kt, 1))
+        # weight gradient tiles (forward grouping)
+        tile_g, tile_col0, g_ncols = gf.wgrad_tiles()
+        self.n_tiles = len(tile_g)
+        self.tile_g, self.tile_col0, self.g_ncols = _dev(tile_g, device), _dev(tile_col0, device), _dev(g_ncols, device)
+        ri = gf.row_id
+        self.dz_rows = _dev(np.where(ri >= 0, y_base[np.maximum(ri, 0)], -1).astype(np.int32), device)
+        self.x_ts, self.y_ts = int(x_ts), int(y_ts)
+        # geometry of the position reduction for the weight gradient
+        self.geom = conv_geom or dict(t_dst=len(pairs_f), t_src=len(pairs_f), stride=1, pad=0, pad_mode=_lib.PAD_REFLECT)
+        self.useful_macs_per_col = gf.useful() * kt * len(pairs_f)      # MACs per batch column, forward
+        self.mfma_macs_per_col = gf.mfma_cost() * kt * len(pairs_f)
+
+    # -- passes --
+    def pack(self, weight):
+        self.fwd.pack(weight)
+        if self.bwd is not None:
+            self.bwd.pack(weight)
+
+    def forward(self, x, y, bp, bias=None, flags=0, slope=0.2):
+        self.fwd.run(x, y, bp, bias, flags, slope)
+
+    def backward_data(self, dy, dx, bp, accumulate=False):
+        self.bwd.run(dy, dx, bp, None, _lib.FLAG_ACCUM if accumulate else 0)
+
+    def n_split(self, bp):
+        return P.pick_split(self.n_tiles, self.geom["t_dst"] * (bp // 16))
+
+    def slab_floats(self, bp):
+        return self.n_split(bp) * self.n_tiles * self.fwd.g.mt * 16 * 64
+
+    def backward_weight(self, dy, x, dw, bp, slab, accumulate=False):
+        lib = _lib.load()
+        g = self.fwd.g
+        ns = self.n_split(bp)
+        assert slab.numel() >= ns * self.n_tiles * g.mt * 16 * 64
+        ge = self.geom
+        d = _lib.WgradDesc(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(slab), _lib.ptr(self.tile_g), _lib.ptr(self.tile_col0),
+                           _lib.ptr(self.g_ncols), _lib.ptr(self.fwd.g_choff), _lib.ptr(self.fwd.chan_rows),
+                           _lib.ptr(self.dz_rows), self.n_tiles, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"],
+                           ge["stride"], ge["pad"], ge["pad_mode"], int(bp), self.y_ts, self.x_ts)
+        _lib.check(lib.hmvae_wgrad_gemm(C.byref(d), _lib.stream()), "wgrad_gemm")
+        n_rows, n_chan, kt = self.w_shape
+        r = _lib.WreduceDesc(_lib.ptr(slab), _lib.ptr(dw), _lib.ptr(self.tile_g), _lib.ptr(self.tile_col0),
+                             _lib.ptr(self.g_ncols), _lib.ptr(self.fwd.g_choff), _lib.ptr(self.fwd.chan_id),
+                             _lib.ptr(self.fwd.row_id), _lib.ptr(self.fwd.g_nc4), _lib.ptr(self.fwd.g_okoff),
+                             _lib.ptr(self.fwd.pair_ok), self.n_tiles, g.mt, g.kt, ns, n_chan * kt, kt,
+                             1 if accumulate else 0)
+        _lib.check(lib.hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce")
+
+
+def conv_gemm(device, neigh, cin, cout, kt, stride, pad, pad_mode, t_in, need_dx=True, out_chan_map=None):
+    """SkeletonConv (skeleton.py:9-105) as a MaskedGemm.  out_chan_map lets the output land in other channel
+    slots (the decoder's per-edge concat, seq_two_hier_sa_vae.py:280-288)."""
+    t_out = (t_in + 2 * pad - kt) // stride + 1
+    mode = "reflect" if pad_mode in ("reflect", "reflection") else "zeros"
+    if mode == "reflect" and pad >= t_in and pad > 0:
+        raise ValueError("reflect padding %d needs more than %d time steps" % (pad, t_in))
+    rows_f, chans_f = P.conv_joint_lists(neigh, cin, cout)
+    rows_b = chans_b = pairs_b = None
+    if need_dx:
+        rows_b, chans_b = P.conv_joint_lists_transposed(neigh, cin, cout)
+        pairs_b = P.conv_pairs_bwd(t_in, t_out, kt, stride, pad, mode)
+    pairs_f = P.conv_pairs_fwd(t_in, t_out, kt, stride, pad, mode)
+    x_base = np.arange(cin, dtype=np.int64) * t_in
+    oc = np.arange(cout, dtype=np.int64) if out_chan_map is None else np.asarray(out_chan_map, dtype=np.int64)
+    y_base = oc * t_out
+    geom = dict(t_dst=t_out, t_src=t_in, stride=stride, pad=pad,
+                pad_mode=_lib.PAD_REFLECT if mode == "reflect" else _lib.PAD_ZEROS)
+    op = MaskedGemm(device, (cout, cin, kt), rows_f, chans_f, rows_b, chans_b, pairs_f, pairs_b, x_base, y_base, 1, 1,
+                    conv_geom=geom)
+    op.t_in, op.t_out = t_in, t_out
+    return op
+
+
+def linear_gemm(device, n_out, n_in, k_edges, x_edge_stride, y_edge_stride, y_offset=0, need_dx=True):
+    """nn.Linear applied per edge to rows that are `edge_stride` apart:  y[e*ys + yo + o] = W[o,:]·x[e*xs + :] + b[o].
+    The edge index plays the role of the conv's position; the weight is shared by all edges."""
+    rows_f, chans_f = [list(range(n_out))], [list(range(n_in))]
+    rows_b, chans_b = ([list(range(n_in))], [list(range(n_out))]) if need_dx else (None, None)
+    pairs = [[(e, 0)] for e in range(k_edges)]
+    x_base = np.arange(n_in, dtype=np.int64)
+    y_base = np.arange(n_out, dtype=np.int64) + y_offset
+    geom = dict(t_dst=k_edges, t_src=k_edges, stride=1, pad=0, pad_mode=_lib.PAD_REFLECT)
+    return MaskedGemm(device, (n_out, n_in, 1), rows_f, chans_f, rows_b, chans_b, pairs, pairs if need_dx else None,
+                      x_base, y_base, x_edge_stride, y_edge_stride, conv_geom=geom)
+
+
+# ---------------------------------------------------------------------------------------------
+# element-wise wrappers
+# ---------------------------------------------------------------------------------------------
+def aos_to_soa(aos, soa, B, T, Cn, bp):
+    _lib.check(_lib.load().hmvae_aos_to_soa(_lib.ptr(aos), _lib.ptr(soa), B, T, Cn, bp, _lib.stream()), "aos_to_soa")
+
+
+def soa_to_aos(soa, aos, B, T, Cn, bp):
+    _lib.check(_lib.load().hmvae_soa_to_aos(_lib.ptr(soa), _lib.ptr(aos), B, T, Cn, bp, _lib.stream()), "soa_to_aos")
+
+
+class PoolOp:
+    """SkeletonPool(mean) + LeakyReLU on SoA rows (skeleton.py:159-231)."""
+
+    def __init__(self, device, pooling_list, n_in_edges, ch):
+        self.n_out, self.n_in, self.ch = len(pooling_list), n_in_edges, ch
+        e1 = [g[0] for g in pooling_list]
+        e2 = [g[1] if len(g) > 1 else -1 for g in pooling_list]
+        if any(len(g) > 2 for g in pooling_list):
+            raise NotImplementedError("pooling groups of more than two edges")
+        dst = np.full(n_in_edges, -1, dtype=np.int32)
+        w = np.zeros(n_in_edges, dtype=np.float32)
+        for i, g in enumerate(pooling_list):
+            for j in g:
+                dst[j] = i
+                w[j] = 1.0 / len(g)
+        self.covered = bool((dst >= 0).all())
+        dst = np.maximum(dst, 0)
+        self.e1, self.e2 = _dev(np.asarray(e1, np.int32), device), _dev(np.asarray(e2, np.int32), device)
+        self.dst_e, self.w_e = _dev(dst, device), _dev(w, device)
+
+    def forward(self, x, y, T, bp, slope=0.2):
+        _lib.check(_lib.load().hmvae_pool_leaky_fwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(self.e1), _lib.ptr(self.e2),
+                                                    self.n_out, self.ch, T, bp, slope, _lib.stream()), "pool_leaky_fwd")
+
+    def backward(self, dy, y, dx, T, bp, slope=0.2):
+        _lib.check(_lib.load().hmvae_pool_leaky_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dx), _lib.ptr(self.dst_e),
+                                                    _lib.ptr(self.w_e), self.n_in, self.ch, T, bp, slope, _lib.stream()),
+                   "pool_leaky_bwd")
+
+
+class UnpoolOp:
+    """[nn.Upsample(x2 linear)] + SkeletonUnpool on SoA rows (skeleton.py:234-261)."""
+
+    def __init__(self, device, pooling_list, ch, up):
+        self.n_in = len(pooling_list)
+        self.n_out = sum(len(g) for g in pooling_list)
+        self.ch, self.up = ch, 1 if up else 0
+        src = np.zeros(self.n_out, dtype=np.int32)
+        off, lst = [0], []
+        for i, g in enumerate(pooling_list):
+            for j in g:
+                src[j] = i
+            lst.extend(g)
+            off.append(len(lst))
+        self.src_e = _dev(src, device)
+        self.fine_off, self.fine_list = _dev(np.asarray(off, np.int32), device), _dev(np.asarray(lst, np.int32), device)
+
+    def forward(self, x, y, t_in, bp):
+        _lib.check(_lib.load().hmvae_upsample_unpool_fwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(self.src_e), self.n_out,
+                                                         self.ch, t_in, self.up, bp, _lib.stream()), "upsample_unpool_fwd")
+
+    def backward(self, dy, dx, t_in, bp):
+        _lib.check(_lib.load().hmvae_upsample_unpool_bwd(_lib.ptr(dy), _lib.ptr(dx), _lib.ptr(self.fine_off),
+                                                         _lib.ptr(self.fine_list), self.n_in, self.ch, t_in, self.up, bp,
+                                                         _lib.stream()), "upsample_unpool_bwd")
+
+
+def leaky_bwd(dout, out, dy, n, slope=0.2):
+    _lib.check(_lib.load().hmvae_leaky_bwd(_lib.ptr(dout), _lib.ptr(out), _lib.ptr(dy), int(n), slope, _lib.stream()),
+               "leaky_bwd")
+
+
+def row_sums(src, dst, rows, n_out, rows_per_out, row_step, n_cols, accumulate=False):
+    _lib.check(_lib.load().hmvae_row_sums(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(rows), n_out, rows_per_out, row_step,
+                                          n_cols, 1 if accumulate else 0, _lib.stream()), "row_sums")
+
+
+def reparam_kl_fwd(dist, eps, z, kl_partial, k_edges, d, B, bp, sample=True):
+    _lib.check(_lib.load().hmvae_reparam_kl_fwd(_lib.ptr(dist), _lib.ptr(eps), _lib.ptr(z), _lib.ptr(kl_partial), k_edges,
+                                                d, B, bp, 1 if sample else 0, _lib.stream()), "reparam_kl_fwd")
+
+
+def reparam_kl_bwd(dist, eps, dz, ddist, k_edges, d, B, bp, use_dz, kl_scale):
+    _lib.check(_lib.load().hmvae_reparam_kl_bwd(_lib.ptr(dist), _lib.ptr(eps), _lib.ptr(dz), _lib.ptr(ddist), k_edges, d,
+                                                B, bp, 1 if use_dz else 0, float(kl_scale), _lib.stream()),
+               "reparam_kl_bwd")
+
+
+def kl_partial_blocks(k_edges, bp):
+    return k_edges * ((bp + 255) // 256)
+
+
+_PARENTS_C = None
+
+
+def _parents_c(parents):
+    arr = (C.c_int32 * len(parents))(*[int(p) for p in parents])
+    return arr
+
+
+def fk_fwd(rot, rot_dim, offsets, offset_stride, parents, n_frames, R_out, pos_out):
+    pc = _parents_c(parents)
+    _lib.check(_lib.load().hmvae_fk_fwd(_lib.ptr(rot), rot_dim, _lib.ptr(offsets), offset_stride, pc, len(parents),
+                                        int(n_frames), _lib.ptr(R_out), _lib.ptr(pos_out), _lib.stream()), "fk_fwd")
+
+
+def fk_bwd(rot, rot_dim, offsets, offset_stride, parents, n_frames, dR, dpos, d_rot):
+    pc = _parents_c(parents)
+    _lib.check(_lib.load().hmvae_fk_bwd(_lib.ptr(rot), rot_dim, _lib.ptr(offsets), offset_stride, pc, len(parents),
+                                        int(n_frames), _lib.ptr(dR), _lib.ptr(dpos), _lib.ptr(d_rot), _lib.stream()),
+               "fk_bwd")
+
+
+def decode_tail_loss(dec, g6, gR, gP, offsets, T, B, bp, s6, sR, sP, ddec, partial):
+    nb = C.c_int32(0)
+    _lib.check(_lib.load().hmvae_decode_tail_loss(_lib.ptr(dec), _lib.ptr(g6), _lib.ptr(gR), _lib.ptr(gP),
+                                                  _lib.ptr(offsets), T, B, bp, s6, sR, sP, _lib.ptr(ddec),
+                                                  _lib.ptr(partial), C.byref(nb), _lib.stream()), "decode_tail_loss")
+    return nb.value
+
+
+def decode_tail_fwd(dec, offsets, T, B, bp, c6, R, pos):
+    _lib.check(_lib.load().hmvae_decode_tail_fwd(_lib.ptr(dec), _lib.ptr(offsets), T, B, bp, _lib.ptr(c6), _lib.ptr(R),
+                                                 _lib.ptr(pos), _lib.stream()), "decode_tail_fwd")
+
+
+def finalize_sum(partial, n_partial, stride, k, scale, out):
+    _lib.check(_lib.load().hmvae_finalize_sums(_lib.ptr(partial), n_partial, stride, k, float(scale), _lib.ptr(out),
+                                               _lib.stream()), "finalize_sums")

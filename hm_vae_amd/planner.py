@@ -1,0 +1,207 @@
+"""Host-side planning for the MFMA kernels: row groups, channel lists, position/tap tables.
+
+Everything here runs once per model (numpy, CPU); the results are small int32 tables that live on the
+device next to the weights.  The kernels that consume them are in csrc/gemm_kernels.hip; the layout is
+specified in include/hmvae.h (hmvae_gemm_desc / hmvae_wgrad_desc).
+
+A *group* is up to 16*mt output rows that share one list of input channels (the union of the neighbour
+channels of the joints whose rows it holds — skeleton.py:34-39).  Grouping decides how much of every
+16x16x4 MFMA is useful work:  cost = (16*mt) * padded_channels summed over groups.
+"""
+import numpy as np
+
+
+class GroupSet:
+    """Row groups + channel lists for one masked dense matrix W[row, chan, tap]."""
+
+    def __init__(self, mt, groups, kt, row_chans=None):
+        """groups: [(rows, chans)]; row_chans: dense row id -> set of channels that row may read (its mask).
+        When rows of several blocks share a group, the union list holds channels that are masked out for some
+        rows: pair_ok marks the (row, channel) pairs that are really in the mask."""
+        self.mt = int(mt)
+        self.kt = int(kt)
+        self.n_groups = len(groups)
+        rows_per = 16 * self.mt
+        row_id = np.full((self.n_groups, rows_per), -1, dtype=np.int32)
+        chan_id, g_choff, g_nc4, g_woff, g_nch = [], [], [], [], []
+        g_okoff, ok_parts = [], []
+        okoff = 0
+        woff = 0
+        for gi, (rows, chans) in enumerate(groups):
+            assert 0 < len(rows) <= rows_per, (len(rows), rows_per)
+            row_id[gi, :len(rows)] = rows
+            nch = len(chans)
+            pad = (-nch) % 4
+            g_choff.append(len(chan_id))
+            chan_id.extend(list(chans) + [-1] * pad)
+            nc4 = (nch + pad) // 4
+            g_nc4.append(nc4)
+            g_nch.append(nch)
+            g_woff.append(woff)
+            woff += nc4 * self.kt * self.mt * 64
+            ok = np.zeros((rows_per, nc4 * 4), dtype=np.uint8)
+            for ri, r in enumerate(rows):
+                if row_chans is None:
+                    ok[ri, :nch] = 1
+                else:
+                    allowed = row_chans[r]
+                    ok[ri, :nch] = [1 if c in allowed else 0 for c in chans]
+            g_okoff.append(okoff)
+            okoff += ok.size
+            ok_parts.append(ok.reshape(-1))
+        self.row_id = row_id.reshape(-1)
+        self.chan_id = np.asarray(chan_id, dtype=np.int32)
+        self.g_choff = np.asarray(g_choff, dtype=np.int32)
+        self.g_nc4 = np.asarray(g_nc4, dtype=np.int32)
+        self.g_nch = np.asarray(g_nch, dtype=np.int32)
+        self.g_woff = np.asarray(g_woff, dtype=np.int32)
+        self.packed_size = int(woff)
+        self.g_okoff = np.asarray(g_okoff, dtype=np.int32)
+        self.pair_ok = np.concatenate(ok_parts) if ok_parts else np.zeros(1, np.uint8)
+        assert woff < 2 ** 31
+
+    def mfma_cost(self):
+        return int((self.g_nc4 * 4).sum()) * 16 * self.mt
+
+    def useful(self):
+        """(row, chan) pairs that are real work."""
+        return int(self.pair_ok.sum())
+
+    # wgrad tiling: 64 (channel,tap) columns per tile
+    def wgrad_tiles(self):
+        tile_g, tile_col0 = [], []
+        for gi in range(self.n_groups):
+            ncols = int(self.g_nch[gi]) * self.kt
+            for c0 in range(0, ncols, 64):
+                tile_g.append(gi)
+                tile_col0.append(c0)
+        return (np.asarray(tile_g, dtype=np.int32), np.asarray(tile_col0, dtype=np.int32),
+                (self.g_nch * self.kt).astype(np.int32))
+
+
+def _merge_units(units, cap):
+    """Greedy agglomeration: merge two units when rows fit and the summed channel lists shrink."""
+    units = [(list(r), set(c)) for r, c in units]
+    while True:
+        best = None
+        for i in range(len(units)):
+            for j in range(i + 1, len(units)):
+                if len(units[i][0]) + len(units[j][0]) > cap:
+                    continue
+                u = units[i][1] | units[j][1]
+                pad4 = lambda n: (n + 3) // 4 * 4
+                gain = pad4(len(units[i][1])) + pad4(len(units[j][1])) - pad4(len(u))
+                if gain > 0 and (best is None or gain > best[0]):
+                    best = (gain, i, j)
+        if best is None:
+            break
+        _, i, j = best
+        merged = (units[i][0] + units[j][0], units[i][1] | units[j][1])
+        units = [u for k, u in enumerate(units) if k not in (i, j)] + [merged]
+    return units
+
+
+def make_groups(joint_rows, joint_chans, kt, mt_choices=(1, 2, 3, 4)):
+    """joint_rows[j]: dense row ids owned by block j; joint_chans[j]: dense channel ids block j reads."""
+    best = None
+    row_chans = {}
+    for rows, chans in zip(joint_rows, joint_chans):
+        fs = frozenset(chans)
+        for r in rows:
+            row_chans[r] = fs
+    # larger tiles reuse the activation operand more; bias the choice slightly towards them
+    eff = {1: 1.10, 2: 1.0, 3: 0.98, 4: 0.97}
+    for mt in mt_choices:
+        cap = 16 * mt
+        units = []
+        for rows, chans in zip(joint_rows, joint_chans):
+            rows = list(rows)
+            n_chunks = -(-len(rows) // cap)
+            for k in range(n_chunks):
+                units.append((rows[k * cap:(k + 1) * cap], list(chans)))
+        units = _merge_units(units, cap)
+        groups = [(r, sorted(c)) for r, c in units]
+        groups.sort(key=lambda g: min(g[0]))
+        gs = GroupSet(mt, groups, kt, row_chans)
+        score = gs.mfma_cost() * eff[mt]
+        if best is None or score < best[0]:
+            best = (score, gs)
+    return best[1]
+
+
+# ---------------------------------------------------------------------------------------------
+# masked conv (SkeletonConv) structure
+# ---------------------------------------------------------------------------------------------
+def conv_joint_lists(neigh, cin, cout):
+    """Per output block i: rows [co*i, co*(i+1)), channels = expanded neighbour list (skeleton.py:34-39)."""
+    n = len(neigh)
+    ci, co = cin // n, cout // n
+    rows = [list(range(co * i, co * (i + 1))) for i in range(n)]
+    chans = [[k * ci + c for k in nb for c in range(ci)] for nb in neigh]
+    return rows, chans
+
+
+def conv_joint_lists_transposed(neigh, cin, cout):
+    """For backward-data: rows are INPUT channels of block k, channels are OUTPUT channels of every block i
+    that lists k as a neighbour."""
+    n = len(neigh)
+    ci, co = cin // n, cout // n
+    rows = [list(range(ci * k, ci * (k + 1))) for k in range(n)]
+    chans = [[] for _ in range(n)]
+    for i, nb in enumerate(neigh):
+        for k in nb:
+            chans[k].extend(range(co * i, co * (i + 1)))
+    return rows, [sorted(c) for c in chans]
+
+
+def reflect(u, n):
+    if u < 0:
+        u = -u
+    if u >= n:
+        u = 2 * (n - 1) - u
+    return u
+
+
+def conv_pairs_fwd(t_in, t_out, kt, stride, pad, pad_mode):
+    """pairs[p] = [(q, tap)]: source position q feeding output position p through tap."""
+    out = []
+    for p in range(t_out):
+        lst = []
+        for tap in range(kt):
+            u = p * stride + tap - pad
+            if 0 <= u < t_in:
+                lst.append((u, tap))
+            elif pad_mode == "reflect":
+                lst.append((reflect(u, t_in), tap))
+        out.append(lst)
+    return out
+
+
+def conv_pairs_bwd(t_in, t_out, kt, stride, pad, pad_mode):
+    """pairs[tau] = [(t, tap)]: output position t whose tap reads input position tau (reflections folded in)."""
+    out = [[] for _ in range(t_in)]
+    for t in range(t_out):
+        for tap in range(kt):
+            u = t * stride + tap - pad
+            if 0 <= u < t_in:
+                out[u].append((t, tap))
+            elif pad_mode == "reflect":
+                out[reflect(u, t_in)].append((t, tap))
+    return out
+
+
+def flatten_pairs(pairs):
+    p_off, p_len, flat = [], [], []
+    for lst in pairs:
+        p_off.append(len(flat))
+        p_len.append(len(lst))
+        flat.extend(q | (tap << 16) for q, tap in lst)
+    if not flat:
+        flat = [0]
+    return (np.asarray(p_off, dtype=np.int32), np.asarray(p_len, dtype=np.int32), np.asarray(flat, dtype=np.int32))
+
+
+def pick_split(n_tiles, k_chunks, target_blocks=1024, max_split=64):
+    """Split of the (position, batch) reduction of the weight-gradient GEMM across workgroups."""
+    s = max(1, min(max_split, -(-target_blocks // max(n_tiles, 1))))
+    return int(max(1, min(s, max(1, k_chunks // 4))))

@@ -1,0 +1,211 @@
+/*
+ * hmvae.h — C ABI of libhmvae_hip.so, the MI355X (gfx950) kernels under the hm-vae training hot path.
+ *
+ * The reference (lijiaman/hm-vae) has no FFI: its "operator interface" is PyTorch modules.  Each entry
+ * point below names the reference code it replaces (paths relative to the reference root).  The
+ * Python side (hm_vae_amd/_lib.py) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it is called `desc` or `*_host`;
+ *   - the caller owns all memory; nothing here allocates, frees or synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t; 0 = default stream) so calls are graph-capturable;
+ *   - return value: HMVAE_OK or a negative HMVAE_ERR_* (hmvae_error_string() gives text); never aborts;
+ *   - activations inside the engine are "SoA": float [rows][Bp], row = channel*T + t (or the strided
+ *     forms described per call), Bp = batch padded to a multiple of 64, batch innermost;
+ *   - "AoS" is the reference's layout: (N, J, 6|9|3) frame-major float.
+ */
+#ifndef HMVAE_H
+#define HMVAE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMVAE_OK 0
+#define HMVAE_ERR_ARG (-1)
+#define HMVAE_ERR_LAUNCH (-2)
+#define HMVAE_ERR_UNSUPPORTED (-3)
+
+#define HMVAE_FLAG_LEAKY 1      /* dst = leaky_relu(acc + bias, slope) */
+#define HMVAE_FLAG_ACCUM 2      /* dst += result (read-modify-write) */
+
+#define HMVAE_PAD_REFLECT 0
+#define HMVAE_PAD_ZEROS 1
+
+typedef void* hmvae_stream_t;   /* hipStream_t */
+
+int hmvae_version(void);
+const char* hmvae_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * Gather-GEMM on fp32 MFMA (v_mfma_f32_16x16x4_f32).  One kernel covers
+ *   SkeletonConv forward            skeleton.py:95-105   (masked weight, reflect pad, stride)
+ *   SkeletonConv backward-data      (autograd of the above)
+ *   nn.Linear latent heads fwd/bwd  seq_two_hier_sa_vae.py:162, 267
+ * dst[dst_rows[g,r] + p*dst_ts][b] (+)= act( bias[g,r] + sum_{(q,tap) in pairs(p)} sum_{c in list(g)}
+ *                                          W[g][c][tap][r] * src[chan_rows[c] + q*src_ts][b] )
+ * Packed weight layout per group: [c4 < nc4][tap < kt][mt][kk(4)*16 + m] (64 floats per MFMA A operand).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* src;        /* [src_rows][bp] */
+    float* dst;              /* [dst_rows][bp] */
+    const float* wp;         /* packed weights */
+    const float* bias;       /* dense bias vector or NULL */
+    const int32_t* bias_idx; /* [n_groups*mt*16] index into bias per packed row (-1: none) */
+    const int32_t* g_nc4;    /* [n_groups] number of 4-channel steps */
+    const int32_t* g_woff;   /* [n_groups] float offset of the group's weights in wp */
+    const int32_t* g_choff;  /* [n_groups] offset of the group's channel list in chan_rows */
+    const int32_t* chan_rows;/* src row base per listed channel (dummy entries point at row 0, weight 0) */
+    const int32_t* dst_rows; /* [n_groups*mt*16] dst row base, or -1 for padding rows */
+    const int32_t* p_off;    /* [n_pos] */
+    const int32_t* p_len;    /* [n_pos] */
+    const int32_t* pairs;    /* q | (tap << 16) */
+    int32_t n_groups, mt, kt, n_pos, bp;
+    int32_t src_ts, dst_ts;  /* row stride per position step on each side */
+    int32_t flags;
+    float slope;
+} hmvae_gemm_desc;
+
+int hmvae_gather_gemm(const hmvae_gemm_desc* desc, hmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight-gradient GEMM (autograd of skeleton.py:95-105 / nn.Linear w.r.t. weight), split over the
+ * (position, batch) reduction into `n_split` slabs, then a deterministic reduce into the dense grad.
+ * slab[s][tile][mt*16][64] = sum_{t,b in split s} dz[dz_rows[g,r] + t*dz_ts][b] *
+ *                                               x[chan_rows[c(col)] + q(t,tap(col))*x_ts][b]
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* dz;         /* [rows][bp] gradient w.r.t. conv output */
+    const float* x;          /* [rows][bp] conv input */
+    float* slab;             /* [n_split][n_tiles][mt*16][64] */
+    const int32_t* tile_g;   /* [n_tiles] group of the tile */
+    const int32_t* tile_col0;/* [n_tiles] first (channel,tap) column of the tile inside its group */
+    const int32_t* g_ncols;  /* [n_groups] number of valid columns = listed channels * kt */
+    const int32_t* g_choff;  /* [n_groups] */
+    const int32_t* chan_rows;/* x row base per listed channel */
+    const int32_t* dz_rows;  /* [n_groups*mt*16] dz row base or -1 */
+    int32_t n_tiles, n_groups, mt, kt, n_split;
+    int32_t t_dst, t_src, stride, pad, pad_mode, bp;
+    int32_t dz_ts, x_ts;
+} hmvae_wgrad_desc;
+
+int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream);
+
+/* dense[row_out[g,r]*row_stride + chan_id[c]*chan_stride + tap] (+)= sum_s slab[s][tile][r][col] */
+typedef struct {
+    const float* slab;
+    float* dense;
+    const int32_t* tile_g;
+    const int32_t* tile_col0;
+    const int32_t* g_ncols;
+    const int32_t* g_choff;
+    const int32_t* chan_id;  /* dense channel index per listed channel, -1 for dummies */
+    const int32_t* row_id;   /* [n_groups*mt*16] dense row index or -1 */
+    const int32_t* g_nc4;    /* [n_groups] */
+    const int32_t* g_okoff;  /* [n_groups] offset into pair_ok */
+    const uint8_t* pair_ok;  /* per group [mt*16][nc4*4]: 1 when (row, channel) is inside the neighbour mask */
+    int32_t n_tiles, mt, kt, n_split;
+    int32_t row_stride, chan_stride;
+    int32_t accumulate;
+} hmvae_wreduce_desc;
+
+int hmvae_wgrad_reduce(const hmvae_wreduce_desc* desc, hmvae_stream_t stream);
+
+/* packed[g][c4][tap][mt][kk*16+m] = dense[row_id*row_stride + chan_id*chan_stride + tap*tap_stride]
+ * (0 for -1 ids and for (row, channel) pairs outside the mask: this is skeleton.py:96 `weight * mask`) */
+int hmvae_pack_weights(const float* dense, float* packed, const int32_t* g_nc4, const int32_t* g_woff,
+                       const int32_t* g_choff, const int32_t* chan_id, const int32_t* row_id,
+                       const int32_t* g_okoff, const uint8_t* pair_ok, int32_t n_groups,
+                       int32_t mt, int32_t kt, int32_t row_stride, int32_t chan_stride, int32_t tap_stride,
+                       int32_t tap_flip, hmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Element-wise / reduction kernels on SoA activations
+ * ------------------------------------------------------------------------------------------------ */
+/* SkeletonPool (mean of <=2 edges) + LeakyReLU: skeleton.py:228-231 + seq_two_hier_sa_vae.py:129.
+ * out[(e'*ch + c)*T + t] = leaky( sum_k in[(src_e[e',k]*ch + c)*T + t] * w[e'] ); src_e2 = -1 for single. */
+int hmvae_pool_leaky_fwd(const float* in, float* out, const int32_t* src_e1, const int32_t* src_e2, int32_t n_out_edges,
+                         int32_t ch, int32_t T, int32_t bp, float slope, hmvae_stream_t stream);
+/* din[(e*ch+c)*T+t] = dout[(dst_e[e]*ch+c)*T+t] * leaky'(out[...]) * w[e] */
+int hmvae_pool_leaky_bwd(const float* dout, const float* out, float* din, const int32_t* dst_e, const float* w_e,
+                         int32_t n_in_edges, int32_t ch, int32_t T, int32_t bp, float slope, hmvae_stream_t stream);
+/* nn.Upsample(x2, linear, align_corners=False) + SkeletonUnpool: seq_two_hier_sa_vae.py:233-242, skeleton.py:258-261.
+ * out[(e*ch+c)*T_out + t] = lerp(in[(src_e[e]*ch+c)*T_in + ...]); up=0 copies (T_out == T_in). */
+int hmvae_upsample_unpool_fwd(const float* in, float* out, const int32_t* src_e, int32_t n_out_edges, int32_t ch,
+                              int32_t T_in, int32_t up, int32_t bp, hmvae_stream_t stream);
+/* transpose of the above: din[(e'*ch+c)*T_in + t] = sum over fine edges e of e' and output positions */
+int hmvae_upsample_unpool_bwd(const float* dout, float* din, const int32_t* fine_off, const int32_t* fine_list,
+                              int32_t n_in_edges, int32_t ch, int32_t T_in, int32_t up, int32_t bp,
+                              hmvae_stream_t stream);
+/* dy = dout * (out > 0 ? 1 : slope)  (LeakyReLU backward from the activation's output) */
+int hmvae_leaky_bwd(const float* dout, const float* out, float* dy, int64_t n, float slope, hmvae_stream_t stream);
+/* dst[i] (+)= sum_{k < rows_per_out} sum_cols src[rows[i] + k*row_step][:]   (bias gradients; padded batch
+ * columns are zero by construction) */
+int hmvae_row_sums(const float* src, float* dst, const int32_t* rows, int32_t n_out, int32_t rows_per_out,
+                   int32_t row_step, int32_t n_cols, int32_t accumulate, hmvae_stream_t stream);
+/* AoS (B, T, C) <-> SoA (C, T, Bp) */
+int hmvae_aos_to_soa(const float* aos, float* soa, int32_t B, int32_t T, int32_t C, int32_t bp, hmvae_stream_t stream);
+int hmvae_soa_to_aos(const float* soa, float* aos, int32_t B, int32_t T, int32_t C, int32_t bp, hmvae_stream_t stream);
+
+/* reparametrize + KL: seq_two_hier_sa_vae.py:419-428.
+ * dist rows: (e*2d + j) mu, (e*2d + d + j) logvar, [rows][bp]; eps AoS (B*k, d); z rows (e*d + j).
+ * kl_partial[block] = sum over the block's columns of -0.5*sum_j(1 + lv - mu^2 - exp(lv))   (b < B only) */
+int hmvae_reparam_kl_fwd(const float* dist, const float* eps, float* z, float* kl_partial, int32_t k_edges, int32_t d,
+                         int32_t B, int32_t bp, int32_t sample, hmvae_stream_t stream);
+/* ddist = dz through z = mu + eps*exp(lv/2) (if use_dz) + kl_scale * dKL/d(mu,lv) */
+int hmvae_reparam_kl_bwd(const float* dist, const float* eps, const float* dz, float* ddist, int32_t k_edges, int32_t d,
+                         int32_t B, int32_t bp, int32_t use_dz, float kl_scale, hmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rotation lift + forward kinematics
+ * ------------------------------------------------------------------------------------------------ */
+/* my_tools.py:19-39 + fk_layer.py:47-93, AoS.  rot: (n, J, rot_dim) with rot_dim 6 or 9; offsets (J,3) shared
+ * (offset_stride 0) or per frame (offset_stride J*3).  R_out (n,J,9) and pos_out (n,J,3) may be NULL.
+ * parents_host: J ints on the HOST; the SMPL-24 tree runs the register-resident fast path. */
+int hmvae_fk_fwd(const float* rot, int32_t rot_dim, const float* offsets, int64_t offset_stride,
+                 const int32_t* parents_host, int32_t n_joints, int64_t n_frames, float* R_out, float* pos_out,
+                 hmvae_stream_t stream);
+/* backward of the above: d_rot (n,J,rot_dim) from dR (n,J,9; may be NULL) and dpos (n,J,3; may be NULL) */
+int hmvae_fk_bwd(const float* rot, int32_t rot_dim, const float* offsets, int64_t offset_stride,
+                 const int32_t* parents_host, int32_t n_joints, int64_t n_frames, const float* dR, const float* dpos,
+                 float* d_rot, hmvae_stream_t stream);
+
+/* seq_two_hier_sa_vae.py:436-474 (decode tail) fused with the three MSEs of :395-397/:430-434 and their
+ * backward: SoA decoder output (144 rows x T) and SoA targets -> per-block loss partials + dL/d(dec_out).
+ * scale_* = weight / numel of each MSE.  partial: [n_blocks][3] sums of squared errors (6d, rot, pos). */
+int hmvae_decode_tail_loss(const float* dec_out, const float* gt6d, const float* gtR, const float* gtP,
+                           const float* offsets, int32_t T, int32_t B, int32_t bp, float scale_6d, float scale_rot,
+                           float scale_pos, float* d_dec_out, float* partial, int32_t* n_blocks_out,
+                           hmvae_stream_t stream);
+/* decode tail, inference: SoA decoder output -> AoS cont6d (B,T,24,6), R (B,T,24,3,3), pos (B,T,24,3) */
+int hmvae_decode_tail_fwd(const float* dec_out, const float* offsets, int32_t T, int32_t B, int32_t bp, float* c6,
+                          float* R, float* pos, hmvae_stream_t stream);
+
+/* out[0..n_out) : fixed-order sums of partial[i*stride + k], scaled */
+int hmvae_finalize_sums(const float* partial, int32_t n_partial, int32_t stride, int32_t k, float scale, float* out,
+                        hmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Adam (torch.optim.Adam semantics: L2 weight decay folded into the gradient) — trainer_motion_vae.py:29-31, 92
+ * One launch over a table of tensors; tensors whose gradient is absent are simply not listed.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+} hmvae_adam_tensor;
+
+/* lr_dev: 1 float, step_dev: 1 int (the step being taken, >= 1) — both on the device so a captured
+ * hipGraph replays with the current values. */
+int hmvae_adam_step(const hmvae_adam_tensor* table_dev, int32_t n_tensors, int64_t max_numel, const float* lr_dev,
+                    const int32_t* step_dev, float beta1, float beta2, float eps, float weight_decay,
+                    hmvae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMVAE_H */

@@ -1,0 +1,97 @@
+"""Numpy emulation of the MFMA kernels' *semantics* (include/hmvae.h), driven by the very same tables the
+device kernels read.  Lets the CPU suite validate planner.py / ops.py table construction against the oracle
+without a GPU.  Test-only."""
+import numpy as np
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def emu_pack(side, dense):
+    g = side.g
+    rs, cs, ts = side.strides
+    dense = dense.reshape(-1)
+    wp = np.zeros(max(g.packed_size, 1), dtype=np.float32)
+    row_id = g.row_id.reshape(g.n_groups, g.mt * 16)
+    for gi in range(g.n_groups):
+        for c4 in range(int(g.g_nc4[gi])):
+            for tap in range(g.kt):
+                for mt in range(g.mt):
+                    for kk in range(4):
+                        cid = g.chan_id[g.g_choff[gi] + c4 * 4 + kk]
+                        for m in range(16):
+                            rid = row_id[gi, mt * 16 + m]
+                            ok = g.pair_ok[g.g_okoff[gi] + (mt * 16 + m) * (int(g.g_nc4[gi]) * 4) + c4 * 4 + kk]
+                            if rid >= 0 and cid >= 0 and ok:
+                                idx = g.g_woff[gi] + ((c4 * g.kt + tap) * g.mt + mt) * 64 + kk * 16 + m
+                                wp[idx] = dense[rid * rs + cid * cs + tap * ts]
+    return wp
+
+
+def emu_gather(side, wp, src, dst, bias=None, leaky=False, accum=False, slope=0.2):
+    """src, dst: numpy [rows, bp]."""
+    g = side.g
+    chan_rows, dst_rows = _np(side.chan_rows), _np(side.dst_rows)
+    bias_idx = _np(side.bias_idx)
+    p_off, p_len, pairs = _np(side.p_off), _np(side.p_len), _np(side.pairs)
+    R = g.mt * 16
+    for gi in range(g.n_groups):
+        nc4 = int(g.g_nc4[gi])
+        W = wp[g.g_woff[gi]:g.g_woff[gi] + nc4 * g.kt * g.mt * 64].reshape(nc4, g.kt, g.mt, 4, 16)
+        rows_src = chan_rows[g.g_choff[gi]:g.g_choff[gi] + nc4 * 4].reshape(nc4, 4)
+        for p in range(side.n_pos):
+            acc = np.zeros((R, src.shape[1]), dtype=np.float64)
+            for i in range(int(p_len[p])):
+                pr = int(pairs[p_off[p] + i])
+                q, tap = pr & 0xffff, pr >> 16
+                for c4 in range(nc4):
+                    for kk in range(4):
+                        w = W[c4, tap, :, kk, :].reshape(R)           # [mt*16 + m]
+                        acc += w[:, None].astype(np.float64) * src[rows_src[c4, kk] + q * side.src_ts][None, :]
+            for r in range(R):
+                dr = dst_rows[gi * R + r]
+                if dr < 0:
+                    continue
+                v = acc[r]
+                if bias is not None and bias_idx[gi * R + r] >= 0:
+                    v = v + bias[bias_idx[gi * R + r]]
+                if leaky:
+                    v = np.where(v > 0, v, v * slope)
+                row = dr + p * side.dst_ts
+                dst[row] = (dst[row] + v) if accum else v
+    return dst
+
+
+def emu_wgrad(op, dy, x, dw):
+    """dy, x: numpy [rows, bp]; writes dense dw (n_rows, n_chan, kt) at masked positions."""
+    g = op.fwd.g
+    ge = op.geom
+    R = g.mt * 16
+    chan_rows, dz_rows = _np(op.fwd.chan_rows), _np(op.dz_rows)
+    row_id = g.row_id.reshape(g.n_groups, R)
+    n_rows, n_chan, kt = op.w_shape
+    dwf = dw.reshape(n_rows, n_chan, kt)
+    for gi in range(g.n_groups):
+        for ci in range(int(g.g_nch[gi])):
+            cid = g.chan_id[g.g_choff[gi] + ci]
+            xr = chan_rows[g.g_choff[gi] + ci]
+            for tap in range(kt):
+                acc = np.zeros(R, dtype=np.float64)
+                for t in range(ge["t_dst"]):
+                    u = t * ge["stride"] + tap - ge["pad"]
+                    if ge["pad_mode"] == 0:
+                        if u < 0:
+                            u = -u
+                        if u >= ge["t_src"]:
+                            u = 2 * (ge["t_src"] - 1) - u
+                    elif u < 0 or u >= ge["t_src"]:
+                        continue
+                    xv = x[xr + u * op.x_ts].astype(np.float64)
+                    for r in range(R):
+                        if dz_rows[gi * R + r] >= 0:
+                            acc[r] += float(np.dot(dy[dz_rows[gi * R + r] + t * op.y_ts].astype(np.float64), xv))
+                for r in range(R):
+                    if row_id[gi, r] >= 0 and g.pair_ok[g.g_okoff[gi] + r * (int(g.g_nc4[gi]) * 4) + ci]:
+                        dwf[row_id[gi, r], cid, tap] = acc[r]
+    return dw

@@ -1,0 +1,132 @@
+"""CPU checks of the host-side planning (hm_vae_amd/planner.py, ops.py tables): the numpy emulation of the
+kernel semantics, fed with the device tables, must reproduce the oracle's SkeletonConv / Linear fwd + bwd."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import hmvae_oracle as O
+from hm_vae_amd import ops, planner, topology
+from emu import emu_pack, emu_gather, emu_wgrad
+from helpers import rel_err
+
+
+def to_soa(x):          # (B, C, T) -> [C*T, bp]
+    B, Cn, T = x.shape
+    bp = ops.pad_batch(B)
+    out = np.zeros((Cn * T, bp), dtype=np.float32)
+    out[:, :B] = x.permute(1, 2, 0).reshape(Cn * T, B).numpy()
+    return out
+
+
+def from_soa(a, B, Cn, T):
+    return torch.from_numpy(a[:, :B].reshape(Cn, T, B)).permute(2, 0, 1).contiguous()
+
+
+def test_topology_matches_oracle():
+    edges = topology.edges_from_parents(topology.SMPL24_PARENTS)
+    assert edges == O.skeleton_edges(O.SMPL24_PARENTS)
+    cur = edges
+    for lvl in range(4):
+        assert topology.find_neighbor(cur, 2) == O.edge_neighbours(cur, 2)
+        a = topology.derive_pooling(cur, last_pool=(lvl == 3))
+        b = O.pool_plan(cur, last_pool=(lvl == 3))
+        assert a[0] == b[0] and a[1] == b[1] and [list(e) for e in a[2]] == [list(e) for e in b[2]]
+        if lvl < 3:
+            cur = a[2]
+    for T in (8, 16, 64):
+        assert topology.stride_schedule(T, 4) == O.level_strides(T, 4)
+
+
+@pytest.mark.parametrize("case", [
+    dict(level=0, ci=2, co=4, K=5, stride=2, T=8, mode="reflect"),      # tiny, strided, reflect
+    dict(level=1, ci=3, co=2, K=3, stride=1, T=4, mode="reflect"),
+    dict(level=2, ci=4, co=8, K=5, stride=1, T=6, mode="zeros"),
+    dict(level=3, ci=4, co=20, K=3, stride=2, T=4, mode="reflect"),     # all-neighbour level, rows > 16
+])
+def test_conv_tables_reproduce_oracle(case):
+    torch.manual_seed(case["level"])
+    edges = topology.edges_from_parents(topology.SMPL24_PARENTS)
+    for _ in range(case["level"]):
+        edges = topology.derive_pooling(edges)[2]
+    neigh = topology.find_neighbor(edges, 2)
+    n = len(neigh)
+    cin, cout, K, s, T = case["ci"] * n, case["co"] * n, case["K"], case["stride"], case["T"]
+    pad = (K - 1) // 2
+    B = 3
+    op = ops.conv_gemm("cpu", neigh, cin, cout, K, s, pad, case["mode"], T, need_dx=True)
+    mask = O.conv_mask(neigh, cin, cout, K)
+    w = (torch.randn(cout, cin, K) * mask).requires_grad_(True)
+    b = torch.randn(cout, requires_grad=True)
+    x = torch.randn(B, cin, T, requires_grad=True)
+    y = O.skel_conv(x, w, mask, b, s, pad, "reflect" if case["mode"] == "reflect" else "constant")
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    T_out = y.shape[2]
+    # forward
+    wp = emu_pack(op.fwd, w.detach().numpy())
+    ys = np.zeros((cout * T_out, ops.pad_batch(B)), dtype=np.float32)
+    emu_gather(op.fwd, wp, to_soa(x.detach()), ys, bias=b.detach().numpy())
+    assert rel_err(from_soa(ys, B, cout, T_out).numpy(), y.detach().numpy()) < 1e-5
+    # backward data
+    wpb = emu_pack(op.bwd, w.detach().numpy())
+    dxs = np.zeros((cin * T, ops.pad_batch(B)), dtype=np.float32)
+    emu_gather(op.bwd, wpb, to_soa(gy), dxs)
+    assert rel_err(from_soa(dxs, B, cin, T).numpy(), x.grad.numpy()) < 1e-5
+    # backward weight
+    dw = np.zeros((cout, cin, K), dtype=np.float32)
+    emu_wgrad(op, to_soa(gy), to_soa(x.detach()), dw)
+    assert rel_err(dw, (w.grad * mask).numpy()) < 1e-5
+    # grouping sanity: every masked (row, chan) pair is covered exactly once
+    g = op.fwd.g
+    cover = np.zeros((cout, cin), dtype=np.int32)
+    rid = g.row_id.reshape(g.n_groups, -1)
+    for gi in range(g.n_groups):
+        rows = rid[gi][rid[gi] >= 0]
+        ch = g.chan_id[g.g_choff[gi]:g.g_choff[gi] + g.g_nc4[gi] * 4]
+        ch = ch[ch >= 0]
+        cover[np.ix_(rows, ch)] += 1
+    assert (cover[mask[:, :, 0].numpy() > 0] == 1).all()
+    assert cover.max() == 1
+
+
+def test_linear_tables_reproduce_oracle():
+    torch.manual_seed(5)
+    B, k_edges, n_in, n_out = 5, 3, 12, 20
+    op = ops.linear_gemm("cpu", n_out, n_in, k_edges, n_in, n_out, need_dx=True)
+    w = torch.randn(n_out, n_in, requires_grad=True)
+    b = torch.randn(n_out, requires_grad=True)
+    x = torch.randn(B, k_edges, n_in, requires_grad=True)
+    y = F.linear(x, w, b)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    bp = ops.pad_batch(B)
+    xs = np.zeros((k_edges * n_in, bp), np.float32)
+    xs[:, :B] = x.detach().reshape(B, -1).t().numpy()
+    ys = np.zeros((k_edges * n_out, bp), np.float32)
+    emu_gather(op.fwd, emu_pack(op.fwd, w.detach().numpy()), xs, ys, bias=b.detach().numpy())
+    assert rel_err(ys[:, :B].T.reshape(B, k_edges, n_out), y.detach().numpy()) < 1e-5
+    gys = np.zeros_like(ys)
+    gys[:, :B] = gy.reshape(B, -1).t().numpy()
+    dxs = np.zeros_like(xs)
+    emu_gather(op.bwd, emu_pack(op.bwd, w.detach().numpy()), gys, dxs)
+    assert rel_err(dxs[:, :B].T.reshape(B, k_edges, n_in), x.grad.numpy()) < 1e-5
+    dw = np.zeros((n_out, n_in, 1), np.float32)
+    emu_wgrad(op, gys, xs, dw)
+    assert rel_err(dw[:, :, 0], w.grad.numpy()) < 1e-5
+
+
+def test_grouping_efficiency_len64():
+    """Record (and bound) how much of the MFMA work is useful for the real len64 layers."""
+    edges = topology.edges_from_parents(topology.SMPL24_PARENTS)
+    topo, neighs = [edges], []
+    for lvl in range(4):
+        neighs.append(topology.find_neighbor(topo[-1], 2))
+        topo.append(topology.derive_pooling(topo[-1], last_pool=(lvl == 3))[2])
+    layers = [(0, 144, 288), (1, 168, 336), (2, 216, 432), (3, 336, 672), (3, 672, 336), (2, 432, 216), (1, 336, 168),
+              (0, 576, 144)]
+    for lvl, cin, cout in layers:
+        rows, chans = planner.conv_joint_lists(neighs[lvl], cin, cout)
+        gs = planner.make_groups(rows, chans, 15)
+        eff = gs.useful() / (gs.mfma_cost())
+        assert eff > 0.55, (lvl, cin, cout, gs.mt, eff)
