@@ -61,7 +61,7 @@ _SIGS = {
     "hmvae_pool_leaky_bwd": ([_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),
     "hmvae_upsample_unpool_fwd": ([_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_upsample_unpool_bwd": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
-    "hmvae_leaky_bwd": ([_ptr, _ptr, _ptr, _i64, _f32, _ptr], _i32),
+    "hmvae_leaky_bwd": ([_ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr], _i32),
     "hmvae_row_sums": ([_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_aos_to_soa": ([_ptr, _ptr, _i32, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_soa_to_aos": ([_ptr, _ptr, _i32, _i32, _i32, _i32, _ptr], _i32),

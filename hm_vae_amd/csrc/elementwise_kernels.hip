@@ -182,22 +182,26 @@ extern "C" int hmvae_upsample_unpool_bwd(const float* dout, float* din, const in
 
 // ---------------- LeakyReLU backward from the output ----------------
 __global__ __launch_bounds__(256) void leaky_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ outv,
-                                                         float* __restrict__ dy, long long n4, float slope) {
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += (long long)gridDim.x * 256) {
-        const f32x4 g = ((const f32x4*)dout)[idx];
-        const f32x4 y = ((const f32x4*)outv)[idx];
+                                                         float* __restrict__ dy, long long len4, long long n_blocks,
+                                                         long long stride4, float slope) {
+    const long long total = len4 * n_blocks;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long blk = idx / len4;
+        const long long o = blk * stride4 + (idx - blk * len4);
+        const f32x4 g = ((const f32x4*)dout)[o];
+        const f32x4 y = ((const f32x4*)outv)[o];
         f32x4 r;
 #pragma unroll
         for (int k = 0; k < 4; ++k) r[k] = g[k] * (y[k] > 0.f ? 1.f : slope);
-        ((f32x4*)dy)[idx] = r;
+        ((f32x4*)dy)[o] = r;
     }
 }
 
-extern "C" int hmvae_leaky_bwd(const float* dout, const float* out, float* dy, int64_t n, float slope,
-                               hmvae_stream_t stream) {
-    if (!dout || !out || !dy || n <= 0 || (n & 3)) return HMVAE_ERR_ARG;
-    hipLaunchKernelGGL(leaky_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dout, out, dy,
-                       (long long)(n / 4), slope);
+extern "C" int hmvae_leaky_bwd(const float* dout, const float* out, float* dy, int64_t block_len, int64_t n_blocks,
+                               int64_t block_stride, float slope, hmvae_stream_t stream) {
+    if (!dout || !out || !dy || block_len <= 0 || n_blocks <= 0 || (block_len & 3) || (block_stride & 3)) return HMVAE_ERR_ARG;
+    hipLaunchKernelGGL(leaky_bwd_kernel, dim3(grid_for(block_len / 4 * n_blocks)), dim3(256), 0, (hipStream_t)stream, dout,
+                       out, dy, (long long)(block_len / 4), (long long)n_blocks, (long long)(block_stride / 4), slope);
     return LAUNCH_OK();
 }
 

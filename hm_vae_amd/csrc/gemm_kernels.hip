@@ -44,11 +44,17 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(hmvae_gemm_desc d) {
     const int src_ts = d.src_ts;
     const int kt = d.kt;
 
-    f32x4 acc[MT][4];
+    // two-level accumulation: `acc` holds the running sum of one 4-channel step (<= kt MFMAs, i.e. a short fp32
+    // fma chain); it is folded into `tot` at every step boundary.  Keeps the rounding error of the K ~ 10^4
+    // contractions at the level of a blocked CPU reduction instead of one long sequential chain.
+    f32x4 acc[MT][4], tot[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) {
+            acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            tot[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 
     if (plen > 0 && wave < nc4) {
         int c4 = wave;
@@ -99,6 +105,15 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(hmvae_gemm_desc d) {
                 for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nx[mt];
                 b_cur = b_nx;
             }
+            if (nc != c4) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        tot[mt][j] += acc[mt][j];
+                        acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+            }
             c4 = nc;
             i = ni;
             more = nvalid;
@@ -111,7 +126,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(hmvae_gemm_desc d) {
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+            f32x4 v = {tot[mt][0][r], tot[mt][1][r], tot[mt][2][r], tot[mt][3][r]};
             *(f32x4*)(mine + (mt * 16 + kk * 4 + r) * 64 + (n << 2)) = v;
         }
     }
@@ -203,11 +218,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
             xrow[nt] = d.chan_rows[choff];
         }
     }
-    f32x4 acc[MT][4];
+    f32x4 acc[MT][4], tot[MT][4];          // two-level accumulation, see gather_gemm_kernel
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < 4; ++nt) {
+            acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            tot[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 
     const int nb16 = bp >> 4;
     const long long total = (long long)d.t_dst * nb16;
@@ -215,6 +233,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
     const int hi = (int)(total * (sp + 1) / d.n_split);
     const float* __restrict__ dzp = d.dz + (kk << 2);
     const float* __restrict__ xp = d.x + (kk << 2);
+    int since_flush = 0;
     for (int chunk = lo + wave; chunk < hi; chunk += 4) {
         const int t = chunk / nb16;
         const int b0 = (chunk - t * nb16) << 4;
@@ -241,7 +260,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(a[mt][j], b[nt][j], acc[mt][nt]);
+        if (++since_flush == 16) {
+            since_flush = 0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    tot[mt][nt] += acc[mt][nt];
+                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+        }
     }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] += tot[mt][nt];
     // acc[mt][nt][r] is row mt*16 + kk*4 + r, column nt*16 + n
     float* mine = red + wave * (MT * 16 * 64);
 #pragma unroll

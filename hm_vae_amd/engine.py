@@ -1,0 +1,454 @@
+"""The fused TwoHierSAVAE step: a fixed sequence of HIP kernel launches over preallocated SoA buffers.
+
+This is the hot path named by BASELINE.json: encoder -> latent heads -> reparametrise/KL -> decoder ->
+rot-6D lift -> FK -> losses, and the hand-ordered backward of all of it, i.e. what the reference does in
+`TwoHierSAVAEModel.forward` (seq_two_hier_sa_vae.py:335-417) including the `l_total.backward()` at :414.
+There is no autograd graph: every backward kernel is launched explicitly, gradients land in views of one flat
+fp32 buffer (the DDP bucket), and the whole sequence is capturable in a hipGraph (torch.cuda.CUDAGraph).
+
+Buffers are "SoA": [rows][Bp], row = channel*T + t, batch innermost, Bp = batch rounded up to 64.
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops, topology
+
+
+class VaePlan:
+    """Static structure for one config (mirrors seq_two_hier_sa_vae.py:53-258)."""
+
+    def __init__(self, hp, parents=topology.SMPL24_PARENTS):
+        L, T = int(hp["num_layers"]), int(hp["train_seq_len"])
+        self.hp, self.L, self.T = hp, L, T
+        self.K = int(hp["kernel_size"])
+        self.pad = (self.K - 1) // 2
+        self.pad_mode = {"zeros": "zeros", "constant": "zeros", "reflection": "reflect", "reflect": "reflect"}[hp["padding_mode"]]
+        self.strides, self.tsteps = topology.stride_schedule(T, L)
+        self.ch_base = [int(hp.get("input_dim", 6)) * (2 ** i) for i in range(L + 1)]
+        self.topo = [topology.edges_from_parents(parents)]
+        self.neigh, self.pooling, self.edge_num = [], [], [len(self.topo[0])]
+        self.enc_cin, self.enc_cout = [], []
+        for i in range(L):
+            self.neigh.append(topology.find_neighbor(self.topo[i], hp["skeleton_dist"]))
+            self.enc_cin.append(self.ch_base[i] * self.edge_num[i])
+            self.enc_cout.append(self.ch_base[i + 1] * self.edge_num[i])
+            _, pl, ne = topology.derive_pooling(self.topo[i], last_pool=(i == L - 1))
+            self.pooling.append(pl)
+            self.topo.append(ne)
+            self.edge_num.append(len(pl))
+        self.channel_list = [self.enc_cin[0]] + self.enc_cout
+        self.dec_ts = list(reversed(self.tsteps))
+        self.dec_cin, self.dec_cout, self.dec_bias, self.dec_up = [], [], [], []
+        for i in range(L):
+            cin = self.channel_list[L - i] * (2 if i == L - 1 else 1)
+            self.dec_cin.append(cin)
+            self.dec_cout.append(cin // 4 if i == L - 1 else cin // 2)
+            self.dec_bias.append(i == 0 or i == L - 1)
+            if T == 8:
+                up = (i != L - 1 and i != 0)
+            elif T == 16:
+                up = (i != L - 1)
+            else:
+                up = True
+            self.dec_up.append(up)
+        self.lat_dim = [int(hp["shallow_latent_d"])] + [int(hp["latent_d"])] * (L - 1)
+        self.feat = [self.ch_base[i + 1] * self.tsteps[i + 1] for i in range(L)]       # Linear in-features, level i
+        self.dec_feat = [self.ch_base[L - i] * self.dec_ts[i] for i in range(L)]        # Linear out-features, dec idx i
+
+
+class VaeEngine:
+    """Owns device tables + workspaces; borrows the parameter tensors from the nn.Modules (dict name -> Parameter)."""
+
+    def __init__(self, hp, params, offsets, device, parents=topology.SMPL24_PARENTS):
+        _lib.load()
+        self.hp, self.device = hp, device
+        self.parents = list(parents)
+        self.p = p = VaePlan(hp, parents)
+        self.params = params                       # name -> tensor (dense layout, reference names)
+        self.offsets = torch.as_tensor(np.asarray(offsets), dtype=torch.float32).contiguous().to(device)
+        L = p.L
+        if L < 2:
+            raise ValueError("num_layers >= 2 expected")
+        self.nj = int(hp["n_joints"])
+        if self.nj != 24 or int(hp["output_dim"]) != 6:
+            raise NotImplementedError("the fused decode tail is specialised for 24 joints x 6D")
+        # ---- encoder ops ----
+        self.enc_conv, self.enc_pool, self.enc_lin = [], [], []
+        for i in range(L):
+            self.enc_conv.append(ops.conv_gemm(device, p.neigh[i], p.enc_cin[i], p.enc_cout[i], p.K, p.strides[i], p.pad,
+                                               p.pad_mode, p.tsteps[i], need_dx=(i > 0)))
+            self.enc_pool.append(ops.PoolOp(device, p.pooling[i], p.edge_num[i], p.enc_cout[i] // p.edge_num[i]))
+            k = p.edge_num[i + 1]
+            self.enc_lin.append(ops.linear_gemm(device, 2 * p.lat_dim[i], p.feat[i], k, p.feat[i], 2 * p.lat_dim[i]))
+        # ---- decoder ops ----
+        self.dec_conv, self.dec_unpool, self.dec_lin = [], [], {}
+        self.cD = p.dec_cout[L - 2] // p.edge_num[1]          # running channels per edge before the concat
+        self.cH = p.ch_base[1]                                # skip (hier_feats[L-1]) channels per edge
+        assert p.dec_cin[L - 1] // p.edge_num[0] == self.cD + self.cH
+        for i in range(L):
+            t_in = p.dec_ts[i]
+            t_conv = 2 * t_in if p.dec_up[i] else t_in
+            assert t_conv == p.dec_ts[i + 1], (i, t_conv, p.dec_ts)
+            lvl = L - 1 - i
+            self.dec_unpool.append(ops.UnpoolOp(device, p.pooling[lvl], p.dec_cin[i] // p.edge_num[lvl], p.dec_up[i]))
+            cmap = None
+            if i == L - 2:      # output lands in the per-edge concat buffer (seq_two_hier_sa_vae.py:280-288)
+                cmap = [(c // self.cD) * (self.cD + self.cH) + (c % self.cD) for c in range(p.dec_cout[i])]
+            self.dec_conv.append(ops.conv_gemm(device, p.neigh[lvl], p.dec_cin[i], p.dec_cout[i], p.K, 1, p.pad, p.pad_mode,
+                                               t_conv, need_dx=True, out_chan_map=cmap))
+        kd = p.edge_num[L]
+        self.dec_lin[0] = ops.linear_gemm(device, p.dec_feat[0], p.lat_dim[L - 1], kd, p.lat_dim[L - 1], p.dec_feat[0])
+        t_cat = p.dec_ts[L - 1]
+        assert p.dec_feat[L - 1] == self.cH * t_cat
+        self.cat_edge_rows = (self.cD + self.cH) * t_cat
+        self.dec_lin[L - 1] = ops.linear_gemm(device, p.dec_feat[L - 1], p.lat_dim[0], p.edge_num[1], p.lat_dim[0],
+                                              self.cat_edge_rows, y_offset=self.cD * t_cat)
+        # the dead middle heads (seq_two_hier_sa_vae.py:264-272 computes them, nothing consumes them) exist only for
+        # Decoder.forward's API; they are built lazily
+        self._ws = {}
+        self._bias_rows = {}
+        self._flat = None
+        self.flops_per_seq = self._count_flops()
+
+    # ------------------------------------------------------------------------------------------
+    def _count_flops(self):
+        """Mask-effective conv FLOPs per sequence, forward (2*MAC), as in SURVEY.md §8(d)."""
+        tot = 0
+        for op in self.enc_conv + self.dec_conv:
+            tot += 2 * op.useful_macs_per_col
+        return tot
+
+    def _rows(self, key, base, count):
+        k = (key, count)
+        if k not in self._bias_rows:
+            self._bias_rows[k] = torch.as_tensor(np.asarray(base, dtype=np.int32)).to(self.device)
+        return self._bias_rows[k]
+
+    def workspace(self, B):
+        if B in self._ws:
+            return self._ws[B]
+        if torch.device(self.device).type != "cuda":
+            raise _lib.HmvaeError("the engine computes on a HIP device only (tables may be planned on CPU for inspection)")
+        p, dev = self.p, self.device
+        bp = ops.pad_batch(B)
+        L = p.L
+
+        def buf(rows):
+            return torch.zeros(int(rows), bp, dtype=torch.float32, device=dev)
+
+        w = {"bp": bp, "B": B}
+        T0 = p.T
+        w["X0"], w["GR"], w["GP"] = buf(144 * T0), buf(216 * T0), buf(72 * T0)
+        w["pos_aos"] = torch.zeros(B * T0, 24, 3, device=dev)
+        for i in range(L):
+            t = p.tsteps[i + 1]
+            w["Y%d" % i], w["dY%d" % i] = buf(p.enc_cout[i] * t), buf(p.enc_cout[i] * t)
+            pc = p.ch_base[i + 1] * p.edge_num[i + 1]
+            w["A%d" % i], w["dA%d" % i] = buf(pc * t), buf(pc * t)
+            k, d = p.edge_num[i + 1], p.lat_dim[i]
+            w["ZD%d" % i], w["dZD%d" % i] = buf(k * 2 * d), buf(k * 2 * d)
+            w["Z%d" % i], w["dZ%d" % i] = buf(k * d), buf(k * d)
+            w["KLP%d" % i] = torch.zeros(ops.kl_partial_blocks(k, bp), device=dev)
+        w["H0"], w["dH0"] = buf(p.edge_num[L] * p.dec_feat[0]), buf(p.edge_num[L] * p.dec_feat[0])
+        for i in range(L):
+            t_conv = p.dec_ts[i + 1]
+            w["U%d" % i], w["dU%d" % i] = buf(p.dec_cin[i] * t_conv), buf(p.dec_cin[i] * t_conv)
+            if i == L - 2:
+                rows = p.edge_num[1] * self.cat_edge_rows
+            else:
+                rows = p.dec_cout[i] * t_conv
+            w["D%d" % i], w["dD%d" % i] = buf(rows), buf(rows)
+        w["MSEP"] = torch.zeros((bp // 64) * T0, 3, device=dev)
+        w["losses"] = torch.zeros(8, device=dev)
+        slab = 1
+        for op in self.enc_conv + self.dec_conv + self.enc_lin + list(self.dec_lin.values()):
+            slab = max(slab, op.slab_floats(bp))
+        w["slab"] = torch.empty(slab, device=dev)
+        self._ws[B] = w
+        return w
+
+    # ------------------------------------------------------------------------------------------
+    # parameters / gradients
+    # ------------------------------------------------------------------------------------------
+    def names(self):
+        p, L = self.p, self.p.L
+        enc_w = ["enc.layers.%d.0.weight" % i for i in range(L)]
+        enc_b = ["enc.layers.%d.0.bias" % i for i in range(L)]
+        dconv = ["dec.layers.%d.%d" % (i, 2 if p.dec_up[i] else 1) for i in range(L)]
+        return enc_w, enc_b, dconv
+
+    def grad_layout(self):
+        """Flat gradient bucket: [always active | active from iteration_interval on | never].  Returns
+        (ordered names, offsets, n_phase1, n_phase2) in floats."""
+        if self._flat is not None:
+            return self._flat
+        p, L = self.p, self.p.L
+        enc_w, enc_b, dconv = self.names()
+        always = []
+        for i in range(L):
+            always += [enc_w[i], enc_b[i]]
+        always += ["enc.latent_enc_layers.%d.%s" % (L - 1, s) for s in ("weight", "bias")]
+        for i in range(L):
+            always.append(dconv[i] + ".weight")
+            if p.dec_bias[i]:
+                always.append(dconv[i] + ".bias")
+        for i in (0, L - 1):
+            always += ["dec.latent_dec_layers.%d.%s" % (i, s) for s in ("weight", "bias")]
+        phase2 = ["enc.latent_enc_layers.0.%s" % s for s in ("weight", "bias")]
+        never = []
+        for i in range(1, L - 1):
+            never += ["enc.latent_enc_layers.%d.%s" % (i, s) for s in ("weight", "bias")]
+            never += ["dec.latent_dec_layers.%d.%s" % (i, s) for s in ("weight", "bias")]
+        order = always + phase2 + never
+        offs, o = {}, 0
+        for n in order:
+            offs[n] = o
+            o += self.params[n].numel()
+            o = (o + 3) // 4 * 4
+        n1 = offs[phase2[0]]
+        n2 = offs[never[0]] if never else o
+        self.flat_grad = torch.zeros(o, dtype=torch.float32, device=self.device)
+        self._flat = (order, offs, n1, n2, set(always), set(phase2), set(never))
+        return self._flat
+
+    def grad_view(self, name):
+        order, offs, *_ = self.grad_layout()
+        t = self.params[name]
+        return self.flat_grad[offs[name]:offs[name] + t.numel()].view(t.shape)
+
+    def assign_grads(self, phase2):
+        """Point .grad of the live parameters at their slice of the flat bucket; the rest get None
+        (torch.optim.Adam skips None-grad params — SURVEY.md §3.1 structural fact 1)."""
+        order, offs, n1, n2, always, ph2, never = self.grad_layout()
+        for n in order:
+            t = self.params[n]
+            if n in always or (phase2 and n in ph2):
+                t.grad = self.grad_view(n)
+            else:
+                t.grad = None
+
+    def active_grad_floats(self, phase2):
+        _, _, n1, n2, *_ = self.grad_layout()
+        return n2 if phase2 else n1
+
+    def pack_weights(self):
+        P = self.params
+        enc_w, _, dconv = self.names()
+        L = self.p.L
+        for i in range(L):
+            self.enc_conv[i].pack(P[enc_w[i]])
+            self.dec_conv[i].pack(P[dconv[i] + ".weight"])
+        for i in (0, L - 1):
+            self.enc_lin[i].pack(P["enc.latent_enc_layers.%d.weight" % i])
+            self.dec_lin[i].pack(P["dec.latent_dec_layers.%d.weight" % i])
+
+    # ------------------------------------------------------------------------------------------
+    # forward pieces
+    # ------------------------------------------------------------------------------------------
+    def stage_batch(self, w, r6, rmat):
+        """AoS (B,T,144)/(B,T,216) device tensors -> SoA inputs/targets; target joint positions by FK
+        (seq_two_hier_sa_vae.py:343)."""
+        B, T, bp = w["B"], self.p.T, w["bp"]
+        ops.aos_to_soa(r6, w["X0"], B, T, 144, bp)
+        ops.aos_to_soa(rmat, w["GR"], B, T, 216, bp)
+        ops.fk_fwd(rmat, 9, self.offsets, 0, self.parents, B * T, None, w["pos_aos"])
+        ops.aos_to_soa(w["pos_aos"], w["GP"], B, T, 72, bp)
+
+    def encode(self, w, heads):
+        p, P, bp = self.p, self.params, w["bp"]
+        enc_w, enc_b, _ = self.names()
+        x = w["X0"]
+        for i in range(p.L):
+            self.enc_conv[i].forward(x, w["Y%d" % i], bp, bias=P[enc_b[i]])
+            self.enc_pool[i].forward(w["Y%d" % i], w["A%d" % i], p.tsteps[i + 1], bp)
+            x = w["A%d" % i]
+        for i in heads:
+            self.enc_lin[i].forward(w["A%d" % i], w["ZD%d" % i], bp, bias=P["enc.latent_enc_layers.%d.bias" % i])
+
+    def decode_feats(self, w):
+        """Decoder.forward (seq_two_hier_sa_vae.py:260-294) from Z{L-1} and Z0; result in D{L-1}."""
+        p, P, bp, L = self.p, self.params, w["bp"], self.p.L
+        _, _, dconv = self.names()
+        self.dec_lin[0].forward(w["Z%d" % (L - 1)], w["H0"], bp, bias=P["dec.latent_dec_layers.0.bias"])
+        self.dec_lin[L - 1].forward(w["Z0"], w["D%d" % (L - 2)], bp, bias=P["dec.latent_dec_layers.%d.bias" % (L - 1)])
+        src = w["H0"]
+        for i in range(L):
+            self.dec_unpool[i].forward(src, w["U%d" % i], p.dec_ts[i], bp)
+            bias = P[dconv[i] + ".bias"] if p.dec_bias[i] else None
+            self.dec_conv[i].forward(w["U%d" % i], w["D%d" % i], bp, bias=bias, flags=_lib.FLAG_LEAKY if i < L - 1 else 0)
+            src = w["D%d" % i]
+
+    # ------------------------------------------------------------------------------------------
+    # the training / validation step
+    # ------------------------------------------------------------------------------------------
+    def train_step(self, r6, rmat, iterations, eps_list=None, backward=True, repack=True):
+        """r6 (B,T,144), rmat (B,T,216): fp32 device tensors.  Returns the `losses` device tensor:
+        [total, kl, rec_6d, rec_rot, rec_pose, kl_level0, kl_deep, 0]."""
+        hp, p, P = self.hp, self.p, self.params
+        L = p.L
+        B, T = r6.shape[0], r6.shape[1]
+        if T != p.T:
+            raise ValueError("sequence length %d != train_seq_len %d" % (T, p.T))
+        w = self.workspace(B)
+        bp = w["bp"]
+        phase2 = iterations >= hp["iteration_interval"]
+        sample = hp["kl_w"] != 0
+        if repack:
+            self.pack_weights()
+        self.stage_batch(w, r6, rmat)
+        self.encode(w, (0, L - 1))
+        # reparametrise in level order 0..L-1 so the generator is consumed like the reference (:359-391)
+        eps = []
+        for i in range(L):
+            k, d = p.edge_num[i + 1], p.lat_dim[i]
+            if eps_list is not None:
+                e = eps_list[i]
+            elif sample:
+                e = torch.randn(B * k, d, device=self.device)
+            else:
+                e = None
+            eps.append(e)
+            if i in (0, L - 1):
+                ops.reparam_kl_fwd(w["ZD%d" % i], e, w["Z%d" % i], w["KLP%d" % i], k, d, B, bp, sample)
+        self.decode_feats(w)
+        n6, nR, nP = B * T * 144, B * T * 216, B * T * 72
+        ops.decode_tail_loss(w["D%d" % (L - 1)], w["X0"], w["GR"], w["GP"], self.offsets, T, B, bp,
+                             hp["rec_6d_w"] / n6, hp["rec_rot_w"] / nR, hp["rec_pose_w"] / nP, w["dD%d" % (L - 1)], w["MSEP"])
+        ls = w["losses"]
+        nblk = w["MSEP"].shape[0]
+        ops.finalize_sum(w["MSEP"], nblk, 3, 0, 1.0 / n6, ls[2:3])
+        ops.finalize_sum(w["MSEP"], nblk, 3, 1, 1.0 / nR, ls[3:4])
+        ops.finalize_sum(w["MSEP"], nblk, 3, 2, 1.0 / nP, ls[4:5])
+        ops.finalize_sum(w["KLP0"], w["KLP0"].numel(), 1, 0, 1.0 / (B * p.edge_num[1]), ls[5:6])
+        ops.finalize_sum(w["KLP%d" % (L - 1)], w["KLP%d" % (L - 1)].numel(), 1, 0, 1.0 / (B * p.edge_num[L]), ls[6:7])
+        # l_kl and l_total (:408-411)
+        torch.add(ls[6] * hp["kl_w"], ls[5], alpha=hp["shallow_kl_w"], out=ls[1])
+        tot = ls[2] * hp["rec_6d_w"] + ls[3] * hp["rec_rot_w"] + ls[4] * hp["rec_pose_w"] + ls[1]
+        ls[0].copy_(tot)
+        if backward:
+            self._backward(w, phase2, eps, B, bp)
+            self.assign_grads(phase2)
+        return ls
+
+    def _wgrad(self, op, dy, x, name, bp, w):
+        op.backward_weight(dy, x, self.grad_view(name), bp, w["slab"])
+
+    def _backward(self, w, phase2, eps, B, bp):
+        hp, p, L = self.hp, self.p, self.p.L
+        enc_w, enc_b, dconv = self.names()
+        # ---------------- decoder ----------------
+        for i in range(L - 1, -1, -1):
+            t_conv = p.dec_ts[i + 1]
+            dy = w["dD%d" % i]
+            if i < L - 1:
+                if i == L - 2:      # only the conv half of each edge's concat block went through LeakyReLU
+                    ops.leaky_bwd(dy, w["D%d" % i], dy, self.cD * t_conv * bp, n_blocks=p.edge_num[1],
+                                  block_stride=self.cat_edge_rows * bp)
+                else:
+                    ops.leaky_bwd(dy, w["D%d" % i], dy, dy.numel())
+            conv = self.dec_conv[i]
+            self._wgrad(conv, dy, w["U%d" % i], dconv[i] + ".weight", bp, w)
+            if p.dec_bias[i]:
+                base = (np.arange(p.dec_cout[i]) * t_conv).astype(np.int32)
+                ops.row_sums(dy, self.grad_view(dconv[i] + ".bias"), self._rows(("dconvb", i), base, len(base)),
+                             p.dec_cout[i], t_conv, 1, bp)
+            conv.backward_data(dy, w["dU%d" % i], bp)
+            dst = w["dH0"] if i == 0 else w["dD%d" % (i - 1)]
+            self.dec_unpool[i].backward(w["dU%d" % i], dst, p.dec_ts[i], bp)
+        # latent decode layers
+        t_cat = p.dec_ts[L - 1]
+        lin = self.dec_lin[L - 1]
+        dcat = w["dD%d" % (L - 2)]
+        self._wgrad(lin, dcat, w["Z0"], "dec.latent_dec_layers.%d.weight" % (L - 1), bp, w)
+        base = (np.arange(p.dec_feat[L - 1]) + self.cD * t_cat).astype(np.int32)
+        ops.row_sums(dcat, self.grad_view("dec.latent_dec_layers.%d.bias" % (L - 1)), self._rows("dlinb_last", base, len(base)),
+                     p.dec_feat[L - 1], p.edge_num[1], self.cat_edge_rows, bp)
+        if phase2:
+            lin.backward_data(dcat, w["dZ0"], bp)
+        lin = self.dec_lin[0]
+        self._wgrad(lin, w["dH0"], w["Z%d" % (L - 1)], "dec.latent_dec_layers.0.weight", bp, w)
+        base = np.arange(p.dec_feat[0]).astype(np.int32)
+        ops.row_sums(w["dH0"], self.grad_view("dec.latent_dec_layers.0.bias"), self._rows("dlinb0", base, len(base)),
+                     p.dec_feat[0], p.edge_num[L], p.dec_feat[0], bp)
+        lin.backward_data(w["dH0"], w["dZ%d" % (L - 1)], bp)
+        # ---------------- reparametrisation + KL ----------------
+        k, d = p.edge_num[L], p.lat_dim[L - 1]
+        ops.reparam_kl_bwd(w["ZD%d" % (L - 1)], eps[L - 1], w["dZ%d" % (L - 1)], w["dZD%d" % (L - 1)], k, d, B, bp, True,
+                           hp["kl_w"] / (B * k))
+        if phase2:
+            k0, d0 = p.edge_num[1], p.lat_dim[0]
+            ops.reparam_kl_bwd(w["ZD0"], eps[0], w["dZ0"], w["dZD0"], k0, d0, B, bp, True, hp["shallow_kl_w"] / (B * k0))
+        # ---------------- encoder ----------------
+        i = L - 1
+        lin = self.enc_lin[i]
+        self._wgrad(lin, w["dZD%d" % i], w["A%d" % i], "enc.latent_enc_layers.%d.weight" % i, bp, w)
+        base = np.arange(2 * d).astype(np.int32)
+        ops.row_sums(w["dZD%d" % i], self.grad_view("enc.latent_enc_layers.%d.bias" % i), self._rows(("elinb", i), base, len(base)),
+                     2 * d, k, 2 * d, bp)
+        lin.backward_data(w["dZD%d" % i], w["dA%d" % i], bp)
+        for i in range(L - 1, -1, -1):
+            if i == 0 and phase2:
+                lin = self.enc_lin[0]
+                k0, d0 = p.edge_num[1], p.lat_dim[0]
+                self._wgrad(lin, w["dZD0"], w["A0"], "enc.latent_enc_layers.0.weight", bp, w)
+                base = np.arange(2 * d0).astype(np.int32)
+                ops.row_sums(w["dZD0"], self.grad_view("enc.latent_enc_layers.0.bias"), self._rows(("elinb", 0), base, len(base)),
+                             2 * d0, k0, 2 * d0, bp)
+                lin.backward_data(w["dZD0"], w["dA0"], bp, accumulate=True)
+            t = p.tsteps[i + 1]
+            self.enc_pool[i].backward(w["dA%d" % i], w["A%d" % i], w["dY%d" % i], t, bp)
+            conv = self.enc_conv[i]
+            x = w["X0"] if i == 0 else w["A%d" % (i - 1)]
+            self._wgrad(conv, w["dY%d" % i], x, enc_w[i], bp, w)
+            base = (np.arange(p.enc_cout[i]) * t).astype(np.int32)
+            ops.row_sums(w["dY%d" % i], self.grad_view(enc_b[i]), self._rows(("econvb", i), base, len(base)), p.enc_cout[i], t,
+                         1, bp)
+            if i > 0:
+                conv.backward_data(w["dY%d" % i], w["dA%d" % (i - 1)], bp)
+
+    # ------------------------------------------------------------------------------------------
+    # inference pieces (test()/gen_seq()/_decode)
+    # ------------------------------------------------------------------------------------------
+    def load_latents(self, w, z0, z_deep):
+        """z0 (B,k1,d0), z_deep (B,kL,d) device tensors -> Z0 / Z{L-1} SoA."""
+        B, bp, L = w["B"], w["bp"], self.p.L
+        ops.aos_to_soa(z0.contiguous(), w["Z0"], B, 1, z0.shape[1] * z0.shape[2], bp)
+        ops.aos_to_soa(z_deep.contiguous(), w["Z%d" % (L - 1)], B, 1, z_deep.shape[1] * z_deep.shape[2], bp)
+
+    def decode(self, z0, z_deep, repack=True):
+        """_decode (seq_two_hier_sa_vae.py:436-474): returns AoS (c6 (B,T,24,6), R (B,T,24,3,3), pos (B,T,24,3))."""
+        B = z0.shape[0]
+        w = self.workspace(B)
+        if repack:
+            self.pack_weights()
+        self.load_latents(w, z0, z_deep)
+        self.decode_feats(w)
+        T = self.p.T
+        c6 = torch.empty(B, T, 24, 6, device=self.device)
+        R = torch.empty(B, T, 24, 3, 3, device=self.device)
+        pos = torch.empty(B, T, 24, 3, device=self.device)
+        ops.decode_tail_fwd(w["D%d" % (self.p.L - 1)], self.offsets, T, B, w["bp"], c6, R, pos)
+        return c6, R, pos
+
+    def encode_batch(self, r6, repack=True):
+        """Encoder.forward on (B,T,144): returns latent (B, C, T') and the list of z distributions (B,k,2d)."""
+        B, T = r6.shape[0], r6.shape[1]
+        w = self.workspace(B)
+        bp, L, p = w["bp"], self.p.L, self.p
+        if repack:
+            self.pack_weights()
+            for i in range(1, L - 1):
+                self.enc_lin[i].pack(self.params["enc.latent_enc_layers.%d.weight" % i])
+        ops.aos_to_soa(r6.contiguous(), w["X0"], B, T, 144, bp)
+        self.encode(w, range(L))
+        zs = []
+        for i in range(L):
+            k, d = p.edge_num[i + 1], p.lat_dim[i]
+            out = torch.empty(B, k * 2 * d, device=self.device)
+            ops.soa_to_aos(w["ZD%d" % i], out, B, 1, k * 2 * d, bp)
+            zs.append(out.reshape(B, k, 2 * d))
+        t = p.tsteps[L]
+        rows = w["A%d" % (L - 1)].shape[0]
+        lat = torch.empty(B, rows, device=self.device)
+        ops.soa_to_aos(w["A%d" % (L - 1)], lat, B, 1, rows, bp)
+        return lat.reshape(B, rows // t, t), zs

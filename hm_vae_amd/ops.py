@@ -254,8 +254,10 @@ class UnpoolOp:
                                                          _lib.stream()), "upsample_unpool_bwd")
 
 
-def leaky_bwd(dout, out, dy, n, slope=0.2):
-    _lib.check(_lib.load().hmvae_leaky_bwd(_lib.ptr(dout), _lib.ptr(out), _lib.ptr(dy), int(n), slope, _lib.stream()),
+def leaky_bwd(dout, out, dy, n, slope=0.2, n_blocks=1, block_stride=None):
+    """n floats per block; n_blocks blocks `block_stride` floats apart (defaults: one contiguous block)."""
+    _lib.check(_lib.load().hmvae_leaky_bwd(_lib.ptr(dout), _lib.ptr(out), _lib.ptr(dy), int(n), int(n_blocks),
+                                           int(block_stride if block_stride is not None else n), slope, _lib.stream()),
                "leaky_bwd")
 
 

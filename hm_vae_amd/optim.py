@@ -1,0 +1,108 @@
+"""HipAdam: torch.optim.Adam semantics and state_dict format, stepped by one HIP kernel launch per step value.
+
+trainer_motion_vae.py:29-31 builds `torch.optim.Adam(params, lr, weight_decay)`; its arithmetic (L2 decay folded
+into the gradient, lerp first moment, bias corrections) is restated in csrc/elementwise_kernels.hip::adam_kernel.
+Parameters whose `.grad` is None are skipped exactly like torch does (no decay, no moment update, step not
+advanced) — the reference relies on that for the never-used latent heads.
+"""
+import ctypes as C
+from collections import defaultdict
+
+import torch
+
+from . import _lib
+
+
+class HipAdam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self._host_step = {}
+        self._cache = {}
+        self._lr_dev = {}
+
+    def _state_for(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st['step'] = torch.tensor(0.0)
+            st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            self._host_step[p] = 0
+        elif p not in self._host_step:
+            self._host_step[p] = int(float(st['step']))
+        return st
+
+    def lr_tensor(self, gi, device):
+        key = (gi, str(device))
+        if key not in self._lr_dev:
+            self._lr_dev[key] = [torch.zeros(1, device=device), None]
+        return self._lr_dev[key]
+
+    def sync_lr(self):
+        """Push the host-side learning rate(s) to their device scalars (call after scheduler.step())."""
+        for gi, group in enumerate(self.param_groups):
+            for (g2, _), slot in self._lr_dev.items():
+                if g2 == gi and slot[1] != group['lr']:
+                    slot[0].fill_(group['lr'])
+                    slot[1] = group['lr']
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closure")
+        lib = _lib.load()
+        for gi, group in enumerate(self.param_groups):
+            active = [p for p in group['params'] if p.grad is not None]
+            if not active:
+                continue
+            if not active[0].is_cuda:
+                raise _lib.HmvaeError("HipAdam needs parameters on a HIP device; there is no CPU path")
+            buckets = defaultdict(list)
+            for p in active:
+                self._state_for(p)
+                buckets[self._host_step[p]].append(p)
+            slot = self.lr_tensor(gi, active[0].device)
+            if slot[1] != group['lr']:
+                slot[0].fill_(group['lr'])
+                slot[1] = group['lr']
+            b1, b2 = group['betas']
+            for stepval, plist in buckets.items():
+                ptrs = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]['exp_avg'].data_ptr(),
+                              self.state[p]['exp_avg_sq'].data_ptr(), p.numel()) for p in plist)
+                ent = self._cache.get(ptrs)
+                if ent is None:
+                    tab = (_lib.AdamTensor * len(plist))()
+                    for i, t in enumerate(ptrs):
+                        tab[i] = _lib.AdamTensor(*t)
+                    ent = dict(tab=torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(plist[0].device),
+                               step=torch.full((1,), stepval, dtype=torch.int32, device=plist[0].device),
+                               host=stepval, max_numel=max(p.numel() for p in plist))
+                    if len(self._cache) > 16:
+                        self._cache.clear()
+                    self._cache[ptrs] = ent
+                if ent['host'] == stepval:
+                    ent['step'].add_(1)
+                else:
+                    ent['step'].fill_(stepval + 1)
+                ent['host'] = stepval + 1
+                _lib.check(lib.hmvae_adam_step(ent['tab'].data_ptr(), len(plist), ent['max_numel'], slot[0].data_ptr(),
+                                               ent['step'].data_ptr(), b1, b2, group['eps'], group['weight_decay'],
+                                               _lib.stream()), "adam_step")
+                for p in plist:
+                    self._host_step[p] = stepval + 1
+        return None
+
+    def state_dict(self):
+        for p, n in self._host_step.items():
+            if p in self.state and len(self.state[p]):
+                self.state[p]['step'] = torch.tensor(float(n))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._host_step, self._cache = {}, {}
+        for group in self.param_groups:
+            for p in group['params']:
+                st = self.state.get(p)
+                if st:
+                    self._host_step[p] = int(float(st['step']))
+                    st['step'] = torch.tensor(float(self._host_step[p]))

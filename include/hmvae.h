@@ -139,8 +139,10 @@ int hmvae_upsample_unpool_fwd(const float* in, float* out, const int32_t* src_e,
 int hmvae_upsample_unpool_bwd(const float* dout, float* din, const int32_t* fine_off, const int32_t* fine_list,
                               int32_t n_in_edges, int32_t ch, int32_t T_in, int32_t up, int32_t bp,
                               hmvae_stream_t stream);
-/* dy = dout * (out > 0 ? 1 : slope)  (LeakyReLU backward from the activation's output) */
-int hmvae_leaky_bwd(const float* dout, const float* out, float* dy, int64_t n, float slope, hmvae_stream_t stream);
+/* dy = dout * (out > 0 ? 1 : slope)  (LeakyReLU backward from the activation's output) on n_blocks blocks of
+ * block_len floats that start `block_stride` floats apart (same addressing for dout, out and dy) */
+int hmvae_leaky_bwd(const float* dout, const float* out, float* dy, int64_t block_len, int64_t n_blocks,
+                    int64_t block_stride, float slope, hmvae_stream_t stream);
 /* dst[i] (+)= sum_{k < rows_per_out} sum_cols src[rows[i] + k*row_step][:]   (bias gradients; padded batch
  * columns are zero by construction) */
 int hmvae_row_sums(const float* src, float* dst, const int32_t* rows, int32_t n_out, int32_t rows_per_out,

@@ -1,0 +1,67 @@
+"""CPU structural checks of the fused engine's planning (no kernels run): construction, buffer/row maps, the flat
+gradient bucket layout and the class surface."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hmvae_oracle as O
+from helpers import GOLDEN, load_cfg, offsets
+
+
+@pytest.mark.parametrize("tag", ["len64", "len8"])
+def test_engine_plans_on_cpu(tag):
+    from hm_vae_amd.trainer_motion_vae import Trainer
+    from hm_vae_amd.engine import VaeEngine
+    from hm_vae_amd import _lib
+    cfg = load_cfg(tag)
+    tr = Trainer(cfg)
+    meta = json.load(open(os.path.join(GOLDEN, "model_meta.json")))[tag]
+    assert list(tr.model.state_dict().keys()) == meta["state_dict_keys"]
+    assert [n for n, p in tr.model.named_parameters() if p.requires_grad] == meta["trainable_order"]
+    eng = VaeEngine(cfg, dict(tr.model.named_parameters()), offsets(), "cpu")
+    plan = O.Plan(cfg)
+    # plan agrees with the oracle's (which is pinned to the reference)
+    p = eng.p
+    assert p.neigh == plan.neigh and p.pooling == plan.pooling
+    assert p.enc_cin == plan.enc_cin and p.enc_cout == plan.enc_cout
+    assert p.dec_cin == plan.dec_cin and p.dec_cout == plan.dec_cout and p.dec_up == plan.dec_up
+    assert p.strides == plan.strides and p.tsteps == plan.tsteps and p.lat_dim == plan.lat_dim
+    # flat gradient bucket: phase-1 prefix excludes exactly the reference's None-grad tensors
+    order, offs, n1, n2, always, ph2, never = eng.grad_layout()
+    trainable = set(meta["trainable_order"])
+    assert set(order) == trainable
+    assert trainable - always == set(meta["p1_none_grad"])
+    assert trainable - always - ph2 == set(meta["p2_none_grad"])
+    assert n1 < n2 <= eng.flat_grad.numel()
+    for n in order:
+        assert offs[n] % 4 == 0
+    # mask-effective forward FLOPs per sequence (225.47 MFLOP for len64 convs)
+    if tag == "len64":
+        assert abs(eng.flops_per_seq / 1e6 - 225.47) < 0.5
+    # no compute without a GPU: loud failure, not a fallback
+    with pytest.raises(_lib.HmvaeError):
+        eng.workspace(4)
+    with pytest.raises(_lib.HmvaeError):
+        tr.model(O.synthetic_batch(2, cfg["train_seq_len"]), cfg, 0)
+
+
+def test_c_abi_exports_match_header():
+    """Every function declared in include/hmvae.h is exported by the built library and bound in _lib."""
+    import re
+    from hm_vae_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "hmvae.h")).read()
+    declared = set(re.findall(r"\b(hmvae_[a-z0-9_]+)\s*\(", hdr))
+    lib = _lib.load()
+    assert declared == set(_lib.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.hmvae_version() >= 1
+    assert b"argument" in lib.hmvae_error_string(-1)
+    # argument validation happens on the host before any launch
+    d = _lib.GemmDesc()
+    import ctypes as C
+    assert lib.hmvae_gather_gemm(C.byref(d), None) == -1

@@ -1,0 +1,358 @@
+"""GPU parity tests, operator level: every HIP kernel (through the C ABI) against the CPU oracle.
+
+Tolerance (BASELINE.json north_star): 1e-4 relative, fp32.  Inputs are seeded; sizes are small enough for
+the oracle to finish in seconds but include ragged batches (B not a multiple of 64, B > 64).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import hmvae_oracle as O
+from helpers import GOLDEN, offsets, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from hm_vae_amd import _lib
+    _lib.require_gpu()
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def soa_from_bct(x, dev):
+    """(B, C, T) cpu -> device [C*T, bp] through the HIP transpose kernel."""
+    from hm_vae_amd import ops
+    B, Cn, T = x.shape
+    bp = ops.pad_batch(B)
+    src = x.contiguous().to(dev)
+    out = torch.full((Cn * T, bp), float("nan"), device=dev)
+    ops.aos_to_soa(src, out, B, 1, Cn * T, bp)
+    return out, bp
+
+
+def bct_from_soa(s, B, Cn, T):
+    from hm_vae_amd import ops
+    out = torch.empty(B, Cn * T, device=s.device)
+    ops.soa_to_aos(s, out, B, 1, Cn * T, s.shape[1])
+    return out.reshape(B, Cn, T).cpu()
+
+
+def test_library_loaded_and_transposes(dev):
+    from hm_vae_amd import ops, _lib
+    assert os.path.exists(_lib.lib_path())
+    for B, T, Cn in ((3, 5, 7), (70, 4, 144), (129, 2, 65)):
+        x = torch.randn(B, T, Cn)
+        bp = ops.pad_batch(B)
+        s = torch.full((Cn * T, bp), float("nan"), device=dev)
+        ops.aos_to_soa(x.to(dev), s, B, T, Cn, bp)
+        ref = torch.zeros(Cn, T, bp)
+        ref[:, :, :B] = x.permute(2, 1, 0)
+        assert torch.equal(s.cpu().reshape(Cn, T, bp), ref)          # padded columns are exact zeros
+        back = torch.empty(B, T, Cn, device=dev)
+        ops.soa_to_aos(s, back, B, T, Cn, bp)
+        assert torch.equal(back.cpu(), x)
+
+
+def _level_neigh(level):
+    from hm_vae_amd import topology
+    edges = topology.edges_from_parents(topology.SMPL24_PARENTS)
+    for _ in range(level):
+        edges = topology.derive_pooling(edges)[2]
+    return topology.find_neighbor(edges, 2)
+
+
+CONV_CASES = [
+    dict(level=0, cin=144, cout=288, K=15, s=2, T=64, B=5, mode="reflect", leaky=False),      # enc0 of len64
+    dict(level=3, cin=336, cout=672, K=15, s=2, T=8, B=70, mode="reflect", leaky=False),       # enc3, pad ~ T
+    dict(level=3, cin=672, cout=336, K=15, s=1, T=8, B=3, mode="reflect", leaky=True),         # dec0
+    dict(level=0, cin=576, cout=144, K=15, s=1, T=64, B=2, mode="reflect", leaky=False),       # dec3 (6 rows/joint)
+    dict(level=1, cin=168, cout=336, K=3, s=2, T=8, B=4, mode="reflect", leaky=False),         # len8 config, K=3
+    dict(level=2, cin=36, cout=72, K=5, s=1, T=6, B=65, mode="zeros", leaky=True),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_skeleton_conv_fwd_bwd(dev, case):
+    from hm_vae_amd import ops, _lib
+    torch.manual_seed(17)
+    neigh = _level_neigh(case["level"])
+    cin, cout, K, s, T, B = (case[k] for k in ("cin", "cout", "K", "s", "T", "B"))
+    pad = (K - 1) // 2
+    mask = O.conv_mask(neigh, cin, cout, K)
+    fan = mask[:, :, 0].sum(1, keepdim=True)[:, :, None] * K
+    w = (torch.randn(cout, cin, K) * mask / fan.sqrt()).requires_grad_(True)
+    b = (0.1 * torch.randn(cout)).requires_grad_(True)
+    x = torch.randn(B, cin, T, requires_grad=True)
+    y = O.skel_conv(x, w, mask, b, s, pad, "reflect" if case["mode"] == "reflect" else "constant")
+    if case["leaky"]:
+        y = F.leaky_relu(y, 0.2)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    T_out = y.shape[2]
+
+    op = ops.conv_gemm(dev, neigh, cin, cout, K, s, pad, case["mode"], T)
+    wd = w.detach().to(dev)
+    # poison masked-out weights: the kernels must apply the mask themselves (skeleton.py:96)
+    wd_poison = wd + (1 - mask.to(dev)) * 3.0
+    op.pack(wd_poison)
+    xs, bp = soa_from_bct(x.detach(), dev)
+    ys = torch.full((cout * T_out, bp), float("nan"), device=dev)
+    op.forward(xs, ys, bp, bias=b.detach().to(dev), flags=_lib.FLAG_LEAKY if case["leaky"] else 0)
+    assert rel_err(bct_from_soa(ys, B, cout, T_out).numpy(), y.detach().numpy()) < TOL
+
+    g_pre = gy if not case["leaky"] else gy * torch.where(y.detach() > 0, torch.ones_like(gy), torch.full_like(gy, 0.2))
+    gys, _ = soa_from_bct(g_pre, dev)
+    if case["leaky"]:                      # exercise the leaky backward kernel too
+        gy_raw, _ = soa_from_bct(gy, dev)
+        tmp = torch.empty_like(gy_raw)
+        ops.leaky_bwd(gy_raw, ys, tmp, tmp.numel())
+        assert rel_err(tmp.cpu().numpy(), gys.cpu().numpy()) < 1e-6
+    dxs = torch.full((cin * T, bp), float("nan"), device=dev)
+    op.backward_data(gys, dxs, bp)
+    assert rel_err(bct_from_soa(dxs, B, cin, T).numpy(), x.grad.numpy()) < TOL
+    # accumulate flag
+    op.backward_data(gys, dxs, bp, accumulate=True)
+    assert rel_err(bct_from_soa(dxs, B, cin, T).numpy(), 2 * x.grad.numpy()) < TOL
+
+    dw = torch.zeros(cout, cin, K, device=dev)
+    slab = torch.empty(op.slab_floats(bp), device=dev)
+    op.backward_weight(gys, xs, dw, bp, slab)
+    assert rel_err(dw.cpu().numpy(), w.grad.numpy()) < TOL
+    assert float((dw.cpu() * (1 - mask)).abs().max()) == 0.0         # masked entries stay exactly zero
+    # bias gradient = row sums over (t, batch)
+    rows = (torch.arange(cout, dtype=torch.int32) * T_out).to(dev)
+    db = torch.empty(cout, device=dev)
+    ops.row_sums(gys, db, rows, cout, T_out, 1, bp)
+    assert rel_err(db.cpu().numpy(), b.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("B,k_edges,n_in,n_out", [(5, 7, 384, 48), (70, 14, 12, 384), (3, 9, 384, 24)])
+def test_linear_per_edge(dev, B, k_edges, n_in, n_out):
+    from hm_vae_amd import ops
+    torch.manual_seed(3)
+    w = (torch.randn(n_out, n_in) / n_in ** 0.5).requires_grad_(True)
+    b = (0.1 * torch.randn(n_out)).requires_grad_(True)
+    x = torch.randn(B, k_edges, n_in, requires_grad=True)
+    y = F.linear(x, w, b)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    op = ops.linear_gemm(dev, n_out, n_in, k_edges, n_in, n_out)
+    op.pack(w.detach().to(dev).reshape(n_out, n_in, 1))
+    xs, bp = soa_from_bct(x.detach().reshape(B, k_edges * n_in, 1), dev)
+    ys = torch.full((k_edges * n_out, bp), float("nan"), device=dev)
+    op.forward(xs, ys, bp, bias=b.detach().to(dev))
+    assert rel_err(bct_from_soa(ys, B, k_edges * n_out, 1).reshape(B, k_edges, n_out).numpy(), y.detach().numpy()) < TOL
+    gys, _ = soa_from_bct(gy.reshape(B, k_edges * n_out, 1), dev)
+    dxs = torch.full((k_edges * n_in, bp), float("nan"), device=dev)
+    op.backward_data(gys, dxs, bp)
+    assert rel_err(bct_from_soa(dxs, B, k_edges * n_in, 1).reshape(B, k_edges, n_in).numpy(), x.grad.numpy()) < TOL
+    dw = torch.zeros(n_out, n_in, 1, device=dev)
+    slab = torch.empty(op.slab_floats(bp), device=dev)
+    op.backward_weight(gys, xs, dw, bp, slab)
+    assert rel_err(dw.cpu().numpy()[:, :, 0], w.grad.numpy()) < TOL
+    rows = torch.arange(n_out, dtype=torch.int32).to(dev)
+    db = torch.empty(n_out, device=dev)
+    ops.row_sums(gys, db, rows, n_out, k_edges, n_out, bp)
+    assert rel_err(db.cpu().numpy(), b.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("level,ch,T,B", [(0, 12, 32, 5), (1, 24, 16, 70), (3, 96, 4, 3)])
+def test_pool_and_unpool(dev, level, ch, T, B):
+    from hm_vae_amd import ops, topology
+    torch.manual_seed(level)
+    edges = topology.edges_from_parents(topology.SMPL24_PARENTS)
+    for _ in range(level):
+        edges = topology.derive_pooling(edges)[2]
+    _, pooling, _ = topology.derive_pooling(edges, last_pool=(level == 3))
+    n_in, n_out = len(edges), len(pooling)
+    x = torch.randn(B, n_in * ch, T, requires_grad=True)
+    Wp = O.pool_matrix(pooling, n_in, ch)
+    y = F.leaky_relu(torch.matmul(Wp, x), 0.2)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    pool = ops.PoolOp(dev, pooling, n_in, ch)
+    xs, bp = soa_from_bct(x.detach(), dev)
+    ys = torch.full((n_out * ch * T, bp), float("nan"), device=dev)
+    pool.forward(xs, ys, T, bp)
+    assert rel_err(bct_from_soa(ys, B, n_out * ch, T).numpy(), y.detach().numpy()) < 1e-6
+    gys, _ = soa_from_bct(gy, dev)
+    dxs = torch.full((n_in * ch * T, bp), float("nan"), device=dev)
+    pool.backward(gys, ys, dxs, T, bp)
+    assert rel_err(bct_from_soa(dxs, B, n_in * ch, T).numpy(), x.grad.numpy()) < 1e-6
+
+    # upsample + unpool (decoder direction): coarse (n_out edges) -> fine (n_in edges)
+    for up in (True, False):
+        z = torch.randn(B, n_out * ch, T, requires_grad=True)
+        Wu = O.unpool_matrix(pooling, ch)
+        zz = F.interpolate(z, scale_factor=2, mode="linear", align_corners=False) if up else z
+        u = torch.matmul(Wu, zz)
+        gu = torch.randn_like(u)
+        u.backward(gu)
+        unp = ops.UnpoolOp(dev, pooling, ch, up)
+        zs, _ = soa_from_bct(z.detach(), dev)
+        T2 = 2 * T if up else T
+        us = torch.full((n_in * ch * T2, bp), float("nan"), device=dev)
+        unp.forward(zs, us, T, bp)
+        assert rel_err(bct_from_soa(us, B, n_in * ch, T2).numpy(), u.detach().numpy()) < 1e-6
+        gus, _ = soa_from_bct(gu, dev)
+        dzs = torch.full((n_out * ch * T, bp), float("nan"), device=dev)
+        unp.backward(gus, dzs, T, bp)
+        assert rel_err(bct_from_soa(dzs, B, n_out * ch, T).numpy(), z.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("B,k_edges,d", [(5, 7, 24), (70, 14, 12), (300, 9, 6)])
+def test_reparam_kl(dev, B, k_edges, d):
+    from hm_vae_amd import ops
+    torch.manual_seed(B)
+    dist = (0.5 * torch.randn(B, k_edges, 2 * d)).requires_grad_(True)
+    eps = torch.randn(B * k_edges, d)
+    mu = dist[:, :, :d].reshape(-1, d)
+    lv = dist[:, :, d:].reshape(-1, d)
+    z = eps * torch.exp(0.5 * lv) + mu
+    kl = O.OracleVAE.kl(lv, mu)
+    gz = torch.randn_like(z)
+    kl_w = 0.37
+    ((z * gz).sum() + kl_w * kl).backward()
+    ds, bp = soa_from_bct(dist.detach().reshape(B, k_edges * 2 * d, 1), dev)
+    zs = torch.full((k_edges * d, bp), float("nan"), device=dev)
+    nblk = ops.kl_partial_blocks(k_edges, bp)
+    part = torch.full((nblk,), float("nan"), device=dev)
+    ops.reparam_kl_fwd(ds, eps.to(dev), zs, part, k_edges, d, B, bp)
+    assert rel_err(bct_from_soa(zs, B, k_edges * d, 1).reshape(B * k_edges, d).numpy(), z.detach().numpy()) < 1e-5
+    out = torch.empty(1, device=dev)
+    ops.finalize_sum(part, nblk, 1, 0, 1.0 / (B * k_edges), out)
+    assert abs(float(out) - float(kl)) < 1e-5 * max(1.0, abs(float(kl)))
+    gzs, _ = soa_from_bct(gz.reshape(B, k_edges * d, 1), dev)
+    dd = torch.full((k_edges * 2 * d, bp), float("nan"), device=dev)
+    ops.reparam_kl_bwd(ds, eps.to(dev), gzs, dd, k_edges, d, B, bp, True, kl_w / (B * k_edges))
+    assert rel_err(bct_from_soa(dd, B, k_edges * 2 * d, 1).reshape(B, k_edges, 2 * d).numpy(), dist.grad.numpy()) < TOL
+    assert float(dd[:, B:].abs().max()) == 0.0 if bp > B else True
+
+
+def test_fk_against_reference_golden(dev):
+    """AoS kernels vs vectors produced by the unmodified reference (tests/golden/fk_rot6d.npz)."""
+    from hm_vae_amd import ops
+    g = np.load(os.path.join(GOLDEN, "fk_rot6d.npz"))
+    off = torch.from_numpy(offsets()).to(dev)
+    par = O.SMPL24_PARENTS
+    r6 = torch.from_numpy(g["r6"]).to(dev)
+    n = r6.shape[0]
+    R = torch.full((n, 24, 9), float("nan"), device=dev)
+    P = torch.full((n, 24, 3), float("nan"), device=dev)
+    ops.fk_fwd(r6, 6, off, 0, par, n, R, P)
+    assert np.abs(R.cpu().numpy().reshape(n, 24, 3, 3) - g["R"]).max() < 1e-6      # incl. degenerate rows: bitwise-level
+    assert np.abs(P.cpu().numpy() - g["P"]).max() < 1e-6
+    # rotation-matrix input path and the rest pose known answer
+    P2 = torch.empty_like(P)
+    ops.fk_fwd(R, 9, off, 0, par, n, None, P2)
+    assert np.abs(P2.cpu().numpy() - g["P"]).max() < 1e-6
+    ident = torch.eye(3, device=dev).reshape(1, 1, 9).repeat(1, 24, 1).contiguous()
+    P3 = torch.empty(1, 24, 3, device=dev)
+    ops.fk_fwd(ident, 9, off, 0, par, 1, None, P3)
+    rest = np.load(os.path.join(GOLDEN, "rest_pose_coord.npy"))
+    assert np.abs(P3.cpu().numpy()[0] - rest).max() < 1e-6
+    # backward: d(sum wR*R + wP*P)/d r6
+    d6 = torch.full((n, 24, 6), float("nan"), device=dev)
+    ops.fk_bwd(r6, 6, off, 0, par, n, torch.from_numpy(g["wR"]).reshape(n, 24, 9).contiguous().to(dev),
+               torch.from_numpy(g["wP"]).to(dev), d6)
+    d6 = d6.cpu().numpy()
+    assert np.isfinite(d6).all()
+    for i in range(n):
+        assert rel_err(d6[i], g["d6"][i]) < TOL, i
+    dR = torch.full((n, 24, 9), float("nan"), device=dev)
+    ops.fk_bwd(R, 9, off, 0, par, n, None, torch.from_numpy(g["wP"]).to(dev), dR)
+    assert rel_err(dR.cpu().numpy().reshape(n, 24, 3, 3), g["dR_fkonly"]) < TOL
+    # per-frame offsets
+    offs = off[None].repeat(n, 1, 1) * torch.linspace(0.5, 1.5, n, device=dev)[:, None, None]
+    P4 = torch.empty_like(P)
+    ops.fk_fwd(r6, 6, offs.contiguous(), 72, par, n, None, P4)
+    ref = torch.stack([O.fk_positions(torch.from_numpy(g["r6"][i:i + 1]), par, offs[i].cpu()) for i in range(n)])[:, 0]
+    assert rel_err(P4.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("B,T", [(3, 8), (70, 5)])
+def test_decode_tail_loss_and_fwd(dev, B, T):
+    from hm_vae_amd import ops
+    torch.manual_seed(B)
+    off_np = offsets()
+    off = torch.from_numpy(off_np)
+    dec = torch.randn(B, 144, T, requires_grad=True)
+    tgt = O.synthetic_batch(B, T, seed=5)
+    g6, gR = tgt[0], tgt[1]
+    gP = O.fk_positions(gR.reshape(B * T, 24, 3, 3), O.SMPL24_PARENTS, off).reshape(B, T, 72)
+    d6 = dec.transpose(1, 2).reshape(B * T, 24, 6)
+    R = O.rot6d_to_matrix(d6)
+    Pp = O.fk_positions(R, O.SMPL24_PARENTS, off)
+    l6 = ((d6.reshape(B, T, -1) - g6) ** 2).mean()
+    lR = ((R.reshape(B, T, -1) - gR) ** 2).mean()
+    lP = ((Pp.reshape(B, T, -1) - gP) ** 2).mean()
+    w6, wR, wP = 1.0, 1.0, 10.0
+    (w6 * l6 + wR * lR + wP * lP).backward()
+    bp = ops.pad_batch(B)
+    decs, _ = soa_from_bct(dec.detach(), dev)
+
+    def tgt_soa(t, Cn):
+        s = torch.empty(Cn * T, bp, device=dev)
+        ops.aos_to_soa(t.contiguous().to(dev), s, B, T, Cn, bp)
+        return s
+
+    g6s, gRs, gPs = tgt_soa(g6, 144), tgt_soa(gR, 216), tgt_soa(gP, 72)
+    dd = torch.full((144 * T, bp), float("nan"), device=dev)
+    part = torch.full(((bp // 64) * T, 3), float("nan"), device=dev)
+    offd = off.to(dev)
+    nb = ops.decode_tail_loss(decs, g6s, gRs, gPs, offd, T, B, bp, w6 / (B * T * 144), wR / (B * T * 216),
+                              wP / (B * T * 72), dd, part)
+    assert nb == part.shape[0]
+    sums = part.double().sum(0).cpu().numpy()
+    assert abs(sums[0] / (B * T * 144) - float(l6)) < TOL * float(l6)
+    assert abs(sums[1] / (B * T * 216) - float(lR)) < TOL * float(lR)
+    assert abs(sums[2] / (B * T * 72) - float(lP)) < TOL * float(lP)
+    assert rel_err(bct_from_soa(dd, B, 144, T).numpy(), dec.grad.numpy()) < TOL
+    if bp > B:
+        assert float(dd[:, B:].abs().max()) == 0.0
+    # inference tail: SoA decoder output -> AoS 6D / R / pos
+    c6o = torch.empty(B, T, 24, 6, device=dev)
+    Ro = torch.empty(B, T, 24, 3, 3, device=dev)
+    Po = torch.empty(B, T, 24, 3, device=dev)
+    ops.decode_tail_fwd(decs, offd, T, B, bp, c6o, Ro, Po)
+    assert rel_err(c6o.cpu().numpy().reshape(B * T, 24, 6), d6.detach().numpy()) < 1e-6
+    assert rel_err(Ro.cpu().numpy().reshape(B * T, 24, 3, 3), R.detach().numpy()) < 1e-5
+    assert rel_err(Po.cpu().numpy().reshape(B * T, 24, 3), Pp.detach().numpy()) < 1e-5
+
+
+def test_adam_matches_torch(dev):
+    import ctypes as C
+    from hm_vae_amd import _lib
+    torch.manual_seed(0)
+    shapes = [(1000,), (37, 5), (3,)]
+    ps = [torch.randn(s) for s in shapes]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    opt = torch.optim.Adam(ref, lr=1e-3, weight_decay=1e-4)
+    dp = [p.clone().to(dev) for p in ps]
+    dm = [torch.zeros_like(p) for p in dp]
+    dv = [torch.zeros_like(p) for p in dp]
+    dg = [torch.zeros_like(p) for p in dp]
+    tab = (_lib.AdamTensor * len(dp))()
+    for i in range(len(dp)):
+        tab[i] = _lib.AdamTensor(dp[i].data_ptr(), dg[i].data_ptr(), dm[i].data_ptr(), dv[i].data_ptr(), dp[i].numel())
+    tab_dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
+    lr_dev = torch.tensor([1e-3], device=dev)
+    step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    for it in range(5):
+        gs = [torch.randn(s) for s in shapes]
+        for r, g, d in zip(ref, gs, dg):
+            r.grad = g.clone()
+            d.copy_(g)
+        opt.step()
+        step_dev += 1
+        _lib.check(_lib.load().hmvae_adam_step(tab_dev.data_ptr(), len(dp), max(p.numel() for p in dp), lr_dev.data_ptr(),
+                                               step_dev.data_ptr(), 0.9, 0.999, 1e-8, 1e-4, _lib.stream()), "adam")
+    for r, d in zip(ref, dp):
+        assert rel_err(d.cpu().numpy(), r.detach().numpy()) < 1e-5

@@ -199,15 +199,8 @@ def test_two_adam_steps_match_reference_trainer(tag):
 def test_decoder_only_sampling_matches_reference(tag):
     g, meta = load_model_golden(tag)
     cfg, plan, m = _oracle(tag)
-    # the reference decoded with weights after two Adam steps; replay them
-    opt, sched = O.make_adam(m, cfg)
-    batch, eps = golden_batch(g), golden_eps(g)
-    for s in range(2):
-        opt.zero_grad()
-        m.train_forward(batch, s, eps)
-        opt.step()
     with torch.no_grad():
         c6, R, pos, _ = m.decode([torch.from_numpy(g["samp|z%d" % i]) for i in range(4)])
-    assert rel_err(c6.numpy(), g["samp|c6"]) < 1e-4
-    assert rel_err(R.numpy(), g["samp|R"]) < 1e-4
+    assert rel_err(c6.numpy(), g["samp|c6"]) < 2e-6
+    assert rel_err(R.numpy(), g["samp|R"]) < 1e-4           # the lift amplifies 1e-6 noise on short 6D vectors
     assert rel_err(pos.numpy(), g["samp|pos"]) < 1e-4

@@ -183,6 +183,16 @@ def model_golden(cfg_name, B, seed):
         none = summarize_grads(named, store, phase + "|grad|")
         meta[phase + "_none_grad"] = none
 
+    # sampled branch of test(): decoder-only from a given z-list with the SEEDED weights (config 4 semantics)
+    g = torch.Generator().manual_seed(seed + 7)
+    zl = [torch.randn(B, plan.edge_num[i + 1], plan.lat_dim[i], generator=g) for i in range(plan.L)]
+    with torch.no_grad():
+        c6, R, pos = model._decode(zl)[:3]
+    for i, z in enumerate(zl):
+        store["samp|z%d" % i] = z.numpy()
+    store["samp|c6"] = c6.numpy()
+    store["samp|R"] = R.numpy()
+    store["samp|pos"] = pos.numpy()
     # two full Trainer.gen_update steps (phase 1) from the seeded state: losses + sampled params
     model.load_state_dict(sd)
     tr2 = RT.Trainer(cfg)
@@ -202,16 +212,6 @@ def model_golden(cfg_name, B, seed):
         store["upd|" + n + "|val"] = v[idx].copy()
         store["upd|" + n + "|delta"] = (v[idx].astype(np.float64) - seeded[n].reshape(-1).numpy()[idx].astype(np.float64))
     meta["lr_after_2"] = tr2.gen_opt.param_groups[0]["lr"]
-    # sampled branch of test(): decoder-only from given z-list (config 4 semantics)
-    g = torch.Generator().manual_seed(seed + 7)
-    zl = [torch.randn(B, plan.edge_num[i + 1], plan.lat_dim[i], generator=g) for i in range(plan.L)]
-    with torch.no_grad():
-        c6, R, pos = tr2.model._decode(zl)[:3]
-    for i, z in enumerate(zl):
-        store["samp|z%d" % i] = z.numpy()
-    store["samp|c6"] = c6.numpy()
-    store["samp|R"] = R.numpy()
-    store["samp|pos"] = pos.numpy()
     return store, meta
 
 
