@@ -1,0 +1,275 @@
+"""bench.py — hm-vae training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): train sequences/sec, len-64 24-joint 6D sequences, TwoHierSAVAE fwd+bwd+Adam,
+configs[1] = len64_no_aug_hm_vae.yaml at batch 256 per GPU (weak scaling: B = 256*N), synthetic AMASS-shaped data
+resident in HBM, fp32.  One process per GPU; for N>1 launch with torch.distributed.run (RCCL all-reduce of the flat
+gradient bucket).  Rank 0 prints ONE JSON line.  Extra objects on that line:
+  roofline      dominant kernel family (fp32-MFMA gather-GEMM / wgrad), mask-effective FLOPs / HIP-event time
+  fk_roofline   fused rot6D->R->FK decode tail at N=262144 frames (config 4), algorithmic bytes / HIP-event time
+  cpu_baseline  the CPU oracle's training step on the host cores (rank 0, N=1 only), bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.3 TB/s achievable with a float4 copy)
+
+
+def synthetic_device_batch(B, T, seed, device):
+    """N(0,1) 6D draws -> valid rotations; built with the HIP lift so no CPU oracle is involved."""
+    from hm_vae_amd import my_tools
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    raw = torch.randn(B * T, 24, 6, generator=g).to(device)
+    R = my_tools.rotation_matrix_from_ortho6d(raw)                       # (B*T,24,3,3)
+    r6 = torch.cat((R[..., :, 0], R[..., :, 1]), dim=-1).reshape(B, T, 144).contiguous()
+    rmat = R.reshape(B, T, 216).contiguous()
+    z72 = torch.zeros(B, T, 72, device=device)
+    root_v = torch.randn(B, T, 3, generator=g).to(device)
+    return (r6, rmat, z72, z72, z72, z72, root_v)
+
+
+class KernelTimer:
+    """HIP-event timing of individual launches on the current stream (the stream the kernels are launched on)."""
+
+    def __init__(self):
+        self.records = []
+
+    def wrap(self, obj, name, label, flops_fn):
+        orig = getattr(obj, name)
+        timer = self
+
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **k)
+            e1.record()
+            timer.records.append((label, e0, e1, flops_fn(*a, **k)))
+            return r
+
+        setattr(obj, name, timed)
+        return orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for label, e0, e1, fl in self.records:
+            ms = e0.elapsed_time(e1)
+            a = agg.setdefault(label, [0.0, 0.0, 0])
+            a[0] += ms
+            a[1] += fl
+            a[2] += 1
+        return agg
+
+
+def instrument_gemms(engine, timer, bp):
+    """Wrap every MFMA launch of the engine; flops = mask-effective 2*MACs of that launch at this batch."""
+    from hm_vae_amd import ops
+    restore = []
+    all_ops = engine.enc_conv + engine.dec_conv + engine.enc_lin + list(engine.dec_lin.values())
+    for op in all_ops:
+        useful_f = 2.0 * op.useful_macs_per_col
+        restore.append((op.fwd, "run", timer.wrap(op.fwd, "run", "gather_gemm_kernel", lambda *a, _f=useful_f, **k: _f * a[2] if len(a) > 2 else 0.0)))
+        if op.bwd is not None:
+            restore.append((op.bwd, "run", timer.wrap(op.bwd, "run", "gather_gemm_kernel", lambda *a, _f=useful_f, **k: _f * a[2] if len(a) > 2 else 0.0)))
+        restore.append((op, "backward_weight", timer.wrap(op, "backward_weight", "wgrad_kernel(+reduce)",
+                                                           lambda *a, _f=useful_f, **k: _f * a[3])))
+    return restore
+
+
+def fk_microbench(device, iters=20):
+    """Config 4 kernel microbench: SoA decoder output (144 x 64 x 4096) -> AoS 6D, R, joint positions."""
+    from hm_vae_amd import ops
+    import numpy as np
+    B, T = 4096, 64
+    bp = ops.pad_batch(B)
+    off = torch.from_numpy(np.load(os.path.join(ROOT, "hm_vae_amd", "assets", "skeleton_offsets.npy"))).to(device)
+    dec = torch.randn(144 * T, bp, device=device)
+    c6 = torch.empty(B, T, 24, 6, device=device)
+    R = torch.empty(B, T, 24, 3, 3, device=device)
+    P = torch.empty(B, T, 24, 3, device=device)
+    for _ in range(3):
+        ops.decode_tail_fwd(dec, off, T, B, bp, c6, R, P)
+    evs = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.decode_tail_fwd(dec, off, T, B, bp, c6, R, P)
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    avg = sum(ms) / len(ms)
+    n = B * T
+    bytes_per_frame = 576 + 864 + 288 + 576          # read 6D SoA; write R, pos and the AoS copy of the 6D output
+    fused_bytes = 1728                                # SURVEY.md §8(d) figure (6D in, R + pos out)
+    # AoS FK kernel (ForwardKinematicsLayer on rotation matrices): 864 B in, 288 B out per frame
+    rot = R.reshape(n, 24, 9)
+    pos = torch.empty(n, 24, 3, device=device)
+    par = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]
+    for _ in range(3):
+        ops.fk_fwd(rot, 9, off, 0, par, n, None, pos)
+    evs2 = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.fk_fwd(rot, 9, off, 0, par, n, None, pos)
+        e1.record()
+        evs2.append((e0, e1))
+    torch.cuda.synchronize()
+    avg2 = sum(a.elapsed_time(b) for a, b in evs2) / len(evs2)
+    return {"kernel": "decode_tail_fwd_kernel", "frames": n, "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
+            "achieved": fused_bytes * n / (avg * 1e-3) / 1e9, "frac": fused_bytes * n / (avg * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "bytes_per_frame_algorithmic": fused_bytes, "bytes_per_frame_moved": bytes_per_frame,
+            "avg_us": avg * 1e3, "traffic": None,
+            "fk_only_aos": {"kernel": "fk_fwd_aos_kernel<9>", "bytes_per_frame": 1152, "avg_us": avg2 * 1e3,
+                            "achieved": 1152 * n / (avg2 * 1e-3) / 1e9, "frac": 1152 * n / (avg2 * 1e-3) / 1e9 / PEAK_HBM_GBS}}
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """The CPU oracle's full training step (fwd + bwd + Adam) on the host cores; bounded sample."""
+    import numpy as np
+    from oracle import hmvae_oracle as O
+    B = 64
+    plan = O.Plan(cfg)
+    off = np.load(os.path.join(ROOT, "hm_vae_amd", "assets", "skeleton_offsets.npy"))
+    m = O.OracleVAE(cfg, O.name_seeded_params(plan), offsets=off)
+    opt, sched = O.make_adam(m, cfg)
+    batch = O.synthetic_batch(B, cfg["train_seq_len"], seed=0)
+    it = cfg["iteration_interval"]
+    times = []
+    t_start = time.time()
+    n = 0
+    while True:
+        t0 = time.time()
+        opt.zero_grad()
+        m.train_forward(batch, it, O.level_eps(plan, B, seed=n))
+        opt.step()
+        dt = time.time() - t0
+        if n >= 1:
+            times.append(dt)
+        n += 1
+        if (time.time() - t_start > budget_s and len(times) >= 2) or len(times) >= 20:
+            break
+    avg = sum(times) / len(times)
+    return {"value": B / avg, "unit": "sequences/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d timed steps of the pure-PyTorch CPU oracle (fwd+bwd+Adam), len64 config, B=%d, after 1 warm-up"
+                      % (len(times), B), "ms_per_step": avg * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="sequences per GPU")
+    ap.add_argument("--config", type=str, default=os.path.join(ROOT, "configs", "len64_no_aug_hm_vae.yaml"))
+    ap.add_argument("--phase", type=int, default=2, choices=(1, 2))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fk", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph (1) or launch eagerly (0)")
+    args = ap.parse_args()
+
+    from hm_vae_amd import ddp, _lib
+    from hm_vae_amd.trainer_motion_vae import Trainer
+    from hm_vae_amd.utils_common import get_config
+    from hm_vae_amd.graph_step import GraphedStep
+
+    rank, world, local = ddp.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    _lib.require_gpu()
+    device = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(device)
+    cfg = get_config(args.config)
+    torch.manual_seed(1234)
+    tr = Trainer(cfg)
+    tr.cuda()
+    ddp.broadcast_parameters([p for p in tr.model.parameters() if p.requires_grad])
+    T = cfg["train_seq_len"]
+    B = args.batch
+    data = synthetic_device_batch(B, T, seed=rank, device=device)
+    it0 = cfg["iteration_interval"] if args.phase == 2 else 0
+
+    step = GraphedStep(tr, cfg, data, it0, use_graph=bool(args.graph))
+    for _ in range(args.warmup):
+        step.run()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step.run()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B * world * args.steps / elapsed
+
+    out = {"metric": "train sequences/sec (len-64, 24-joint, TwoHierSAVAE fwd+bwd+Adam)", "value": value,
+           "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "len64_no_aug_hm_vae.yaml, batch %d per GPU, T=64, J=24, 6D; phase %d (iterations >= "
+                                  "iteration_interval)" % (B, args.phase) if args.phase == 2 else
+                      "len64_no_aug_hm_vae.yaml, batch %d per GPU, phase 1" % B,
+                      "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world,
+                      "launch": "hipGraph replay" if args.graph else "eager"},
+           "loss_total": float(losses[0])}
+
+    if rank == 0 and not args.no_kernel_timing:
+        # instrumented extra steps (eager, same workload): per-launch HIP events around every MFMA kernel
+        eng = tr.model.engine()
+        timer = KernelTimer()
+        bp = eng.workspace(B)["bp"]
+        restore = instrument_gemms(eng, timer, bp)
+        eager = GraphedStep(tr, cfg, data, it0, use_graph=False)
+        n_inst = 5
+        for _ in range(n_inst):
+            eager.run()
+        agg = timer.summary()
+        for obj, name, orig in restore:
+            setattr(obj, name, orig)
+        fam = max(agg.items(), key=lambda kv: kv[1][0])
+        label, (ms, fl, cnt) = fam
+        tfl = fl / (ms * 1e-3) / 1e12
+        out["roofline"] = {"kernel": label, "bound": "mfma", "achieved": tfl, "peak": PEAK_F32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": tfl / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "launches_per_step": cnt // n_inst, "avg_launch_us": ms / cnt * 1e3,
+                           "flops_per_step_effective": fl / n_inst,
+                           "all_kernels": {k: {"ms_per_step": v[0] / n_inst, "TFLOP/s": v[1] / (v[0] * 1e-3) / 1e12}
+                                           for k, v in agg.items()}}
+        conv_flops_step = 3.0 * eng.flops_per_seq * B
+        out["roofline"]["step_level"] = {"conv_flops_per_step_effective": conv_flops_step,
+                                         "achieved_TFLOP/s": conv_flops_step / (ms_per_step * 1e-3) / 1e12,
+                                         "frac": conv_flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    if rank == 0 and not args.no_fk:
+        out["fk_roofline"] = fk_microbench(device)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

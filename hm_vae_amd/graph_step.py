@@ -1,0 +1,97 @@
+"""hipGraph replay of the training step (torch.cuda.CUDAGraph = hipGraph on ROCm).
+
+The fused engine issues ~170 short kernel launches per step; captured once, a step becomes one graph launch plus
+one 32-byte device->host copy of the loss scalars.  Under DDP the step is captured as two graphs (forward+backward,
+optimiser) with the RCCL all-reduce of the flat gradient bucket launched eagerly between them.
+"""
+import torch
+
+from . import ddp
+
+
+class GraphedStep:
+    def __init__(self, trainer, cfg, data, iterations, use_graph=True, warmup=3):
+        self.tr, self.cfg = trainer, cfg
+        self.model = trainer._this_model()
+        self.it = int(iterations)
+        self.use_graph = bool(use_graph)
+        dev = next(self.model.parameters()).device
+        # static input buffers: the graph reads these addresses on every replay
+        self.r6 = data[0].to(device=dev, dtype=torch.float32).contiguous().clone()
+        self.rmat = data[1].to(device=dev, dtype=torch.float32).contiguous().clone()
+        self.data = (self.r6, self.rmat) + tuple(data[2:])
+        self.graphs = None
+        self.phase2 = None
+        self.warmup = warmup
+
+    def set_batch(self, data):
+        self.r6.copy_(data[0], non_blocking=True)
+        self.rmat.copy_(data[1], non_blocking=True)
+
+    # -- the step body, split at the collective --
+    def _fwd_bwd(self):
+        eng = self.model.engine()
+        self.losses = eng.train_step(self.r6, self.rmat, self.it, eps_list=None, backward=True)
+
+    def _optim(self):
+        self.tr.gen_opt.step()
+
+    def _reduce(self):
+        if ddp.is_distributed():
+            eng = self.model.engine()
+            ddp.all_reduce_mean_(eng.flat_grad[:eng.active_grad_floats(self.phase2)])
+
+    def _capture(self):
+        self.phase2 = self.it >= self.cfg['iteration_interval']
+        # warm up eagerly on a side stream: creates workspaces, index tables and the Adam state outside the graph
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(self.warmup):
+                self._fwd_bwd()
+                self._reduce()
+                self._optim()
+                self.tr.gen_opt.advance_host_steps(0)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        g2 = None
+        if ddp.is_distributed():
+            with torch.cuda.graph(g1):
+                self._fwd_bwd()
+            g2 = torch.cuda.CUDAGraph()
+            host_before = dict(self.tr.gen_opt._host_step)
+            with torch.cuda.graph(g2):
+                self._optim()
+            self.tr.gen_opt._host_step = host_before        # capture does not execute: undo the host-side count
+            self.tr.gen_opt.resync_device_steps()
+        else:
+            host_before = dict(self.tr.gen_opt._host_step)
+            with torch.cuda.graph(g1):
+                self._fwd_bwd()
+                self._optim()
+            self.tr.gen_opt._host_step = host_before
+            self.tr.gen_opt.resync_device_steps()
+        self.graphs = (g1, g2)
+
+    def run(self):
+        """One training step; returns the nine loss floats like Trainer.gen_update."""
+        if not self.use_graph:
+            out = self.tr.gen_update(self.data, self.cfg, self.it, False)
+            self.it += 1
+            return out
+        if self.graphs is None or self.phase2 != (self.it >= self.cfg['iteration_interval']):
+            self._capture()
+        g1, g2 = self.graphs
+        g1.replay()
+        if g2 is not None:
+            self._reduce()
+            g2.replay()
+        opt = self.tr.gen_opt
+        opt.advance_host_steps(1)
+        if self.tr.gen_scheduler is not None:
+            self.tr.gen_scheduler.step()
+            opt.sync_lr()
+        self.it += 1
+        ls = self.losses.tolist()           # the step's only host synchronisation
+        return (ls[0], ls[1], ls[2], ls[3], ls[4], 0.0, 0.0, 0.0, 0.0)

@@ -75,7 +75,7 @@ class HipAdam(torch.optim.Adam):
                         tab[i] = _lib.AdamTensor(*t)
                     ent = dict(tab=torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(plist[0].device),
                                step=torch.full((1,), stepval, dtype=torch.int32, device=plist[0].device),
-                               host=stepval, max_numel=max(p.numel() for p in plist))
+                               host=stepval, max_numel=max(p.numel() for p in plist), params=list(plist), live=False)
                     if len(self._cache) > 16:
                         self._cache.clear()
                     self._cache[ptrs] = ent
@@ -90,6 +90,24 @@ class HipAdam(torch.optim.Adam):
                 for p in plist:
                     self._host_step[p] = stepval + 1
         return None
+
+    def advance_host_steps(self, n):
+        """A graph replay advances the device step counters but not the host mirror; account for it here."""
+        if not n:
+            return
+        for ent in self._cache.values():
+            if ent.get('live'):
+                ent['host'] += n
+                for p in ent['params']:
+                    self._host_step[p] += n
+
+    def resync_device_steps(self):
+        """After a graph capture (which records the counter increments without executing them) make the host
+        mirror and the device counters agree again, and mark the captured entries as the live ones."""
+        for ent in self._cache.values():
+            ent['host'] = self._host_step[ent['params'][0]]
+            ent['step'].fill_(ent['host'])
+            ent['live'] = all(p.grad is not None for p in ent['params'])
 
     def state_dict(self):
         for p, n in self._host_step.items():
