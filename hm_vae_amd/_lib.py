@@ -28,6 +28,14 @@ class GemmDesc(C.Structure):
                 ("src_ts", _i32), ("dst_ts", _i32), ("flags", _i32), ("slope", _f32)]
 
 
+class Gemm2Desc(C.Structure):
+    _fields_ = [("src", _ptr), ("dst", _ptr), ("wp", _ptr), ("bias", _ptr), ("bias_idx", _ptr), ("g_nc4", _ptr),
+                ("g_woff", _ptr), ("g_choff", _ptr), ("chan_rows", _ptr), ("dst_rows", _ptr), ("pb_off", _ptr),
+                ("pb_len", _ptr), ("items", _ptr), ("n_groups", _i32), ("mt", _i32), ("kt", _i32), ("n_pos", _i32),
+                ("bp", _i32), ("np", _i32), ("n_pblk", _i32), ("n_units", _i32), ("ksplit", _i32), ("max_items", _i32), ("max_nc4", _i32), ("src_ts", _i32),
+                ("dst_ts", _i32), ("flags", _i32), ("slope", _f32)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [("dz", _ptr), ("x", _ptr), ("slab", _ptr), ("tile_g", _ptr), ("tile_col0", _ptr), ("g_ncols", _ptr),
                 ("g_choff", _ptr), ("chan_rows", _ptr), ("dz_rows", _ptr), ("n_tiles", _i32), ("n_groups", _i32),
@@ -54,6 +62,7 @@ _SIGS = {
     "hmvae_version": ([], _i32),
     "hmvae_error_string": ([_i32], C.c_char_p),
     "hmvae_gather_gemm": ([C.POINTER(GemmDesc), _ptr], _i32),
+    "hmvae_gather_gemm_v2": ([C.POINTER(Gemm2Desc), _ptr], _i32),
     "hmvae_wgrad_gemm": ([C.POINTER(WgradDesc), _ptr], _i32),
     "hmvae_wgrad_reduce": ([C.POINTER(WreduceDesc), _ptr], _i32),
     "hmvae_pack_weights": ([_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),

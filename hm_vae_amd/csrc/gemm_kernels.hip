@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(hmvae_gemm_desc d) {
     const int ct = bid % n_ct;
     const int p = bid / n_ct;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: keeps the K loop uniform
     const int kk = lane >> 4;
     const int n = lane & 15;
 
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
     const int g = d.tile_g[tile];
     const int col0 = d.tile_col0[tile];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: keeps the K loop uniform
     const int kk = lane >> 4;
     const int n = lane & 15;
     const int bp = d.bp;

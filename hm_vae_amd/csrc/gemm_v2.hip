@@ -1,0 +1,265 @@
+// gemm_v2.hip — gather-GEMM, second generation: register blocking over output positions.
+//
+// Same contract as hmvae_gather_gemm (SkeletonConv forward / backward-data, per-edge Linear; reference
+// skeleton.py:95-105, seq_two_hier_sa_vae.py:162,267) with three changes that the first rocprof pass asked for:
+//   * a wave owns NP consecutive output positions of one (row group, 64-column batch tile).  One 16-byte
+//     activation load (source position q) now feeds the MFMAs of every position whose window contains q, each
+//     with its own tap's weights: activation traffic per MFMA drops ~NP x (the v1 kernel was L1-bound).
+//   * loads run two "items" ahead of the MFMAs (explicit register ring), so a single wave per SIMD keeps the
+//     matrix pipe fed without relying on occupancy.
+//   * work units are dealt to the 8 XCDs in group-major contiguous ranges (blockIdx % 8 picks the range), so one
+//     XCD's L2 only ever sees the packed weights of its own few row groups.
+// K can still be split over the 4 waves of a workgroup (ksplit = 4, summed through LDS) for the layers whose
+// grids would otherwise not fill 256 CUs; with ksplit = 1 a workgroup is a single wave and uses no LDS at all.
+#include <hip/hip_runtime.h>
+#include "hmvae.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int MAX_ITEMS = 256;      // items per position block (host checks)
+constexpr int MAX_C4 = 512;         // 4-channel steps per group (host checks)
+constexpr int TABLE_INTS = 2 * MAX_ITEMS + 4 * MAX_C4;
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int MT, int NP>
+struct VStage {          // operands of one item, in flight between its loads and its MFMAs
+    f32x4 b;
+    float a[NP][MT];
+};
+struct SStage {          // the item's table entries, read from the LDS copies of the tables
+    int q, taps, c4;
+    int row;             // this lane's source row base (channel kk of the 4-channel step)
+};
+
+template <int MT, int NP>
+__global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int nw = blockDim.x >> 6;
+    const int per = (d.n_units + 7) >> 3;
+    const int u = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per || u >= d.n_units) return;
+    const int n_ct = d.bp >> 6;
+    const int ct = u % n_ct;
+    const int r0 = u / n_ct;
+    const int pb = r0 % d.n_pblk;
+    const int g = r0 / d.n_pblk;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: keeps the K loop uniform
+    const int kk = lane >> 4;
+    const int n = lane & 15;
+
+    const int nc4 = d.g_nc4[g];
+    const int choff = d.g_choff[g];
+    const int nitems = d.pb_len[pb];
+    // tables -> LDS (uniform/broadcast ds_reads in the loop instead of scalar-memory loads with their waits)
+    int* lds_items = (int*)red;                       // [nitems][2]
+    int* lds_rows = lds_items + 2 * MAX_ITEMS;        // [nc4*4]
+    {
+        const int* gi = d.items + 2 * d.pb_off[pb];
+        for (int i = threadIdx.x; i < 2 * nitems; i += blockDim.x) lds_items[i] = gi[i];
+        const int* gr = d.chan_rows + choff;
+        for (int i = threadIdx.x; i < 4 * nc4; i += blockDim.x) lds_rows[i] = gr[i];
+    }
+    __syncthreads();
+    const float* __restrict__ wg = d.wp + d.g_woff[g] + lane;
+    const float* __restrict__ srcc = d.src + (ct << 6) + (n << 2);
+    const int bp = d.bp;
+    const int src_ts = d.src_ts;
+    const int kt = d.kt;
+
+    f32x4 acc[NP][MT][4], tot[NP][MT][4];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[pl][mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                tot[pl][mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+
+    const int n_mine = wave < nc4 ? (nc4 - wave + nw - 1) / nw : 0;
+    const int total = n_mine * nitems;
+    if (total > 0) {
+        // Software pipeline, three stages per item:  S (scalar table reads) -> V (vector operand loads) -> M (MFMAs).
+        // S runs 3 items ahead of M, V runs 2 items ahead.  The steady-state loop body is branch-free straight-line
+        // code over three statically named register sets, so the compiler's s_waitcnt insertion sees a regular
+        // stream and emits counted vmcnt waits (a conditional or a register copy of an in-flight load makes it
+        // fall back to vmcnt(0), which serialises everything).  The iterator is clamped at the last item, so the
+        // pipeline's over-fetch at the tail re-reads valid addresses and is simply never consumed.
+        int lc4 = wave, lit = 0;
+        auto s_fetch = [&](SStage& s) {
+            const int2 it = *(const int2*)(lds_items + 2 * lit);
+            s.q = it.x;
+            s.taps = it.y;
+            s.c4 = lc4;
+            s.row = lds_rows[lc4 * 4 + kk];
+            const int nl = lit + 1;
+            const bool wrap = nl == nitems;
+            const int nc = wrap ? lc4 + nw : lc4;
+            const bool ok = nc < nc4;
+            lit = ok ? (wrap ? 0 : nl) : lit;
+            lc4 = ok ? nc : lc4;
+        };
+        auto v_issue = [&](const SStage& s, VStage<MT, NP>& v) {
+            v.b = *(const f32x4*)(srcc + (size_t)(s.row + s.q * src_ts) * bp);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                int tap = (s.taps >> (8 * pl)) & 0xff;
+                tap = tap == 0xff ? 0 : tap;
+                const float* wc = wg + (size_t)(s.c4 * kt + tap) * (MT * 64);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) v.a[pl][mt] = wc[mt * 64];
+            }
+        };
+        auto mfma = [&](const VStage<MT, NP>& v, int taps) {
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                if (NP == 1 || ((__builtin_amdgcn_readfirstlane(taps) >> (8 * pl)) & 0xff) != 0xff) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[pl][mt][j] = MFMA16(v.a[pl][mt], v.b[j], acc[pl][mt][j]);
+                }
+            }
+        };
+        auto flush = [&]() {     // fold the short fp32 chain into the running total (two-level accumulation)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        tot[pl][mt][j] += acc[pl][mt][j];
+                        acc[pl][mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+        };
+        VStage<MT, NP> v0, v1, v2;
+        SStage c0, c1, c2, n0, n1, n2;
+        int t0, t1, t2;
+        s_fetch(c0); v_issue(c0, v0); t0 = c0.taps;
+        s_fetch(c1); v_issue(c1, v1); t1 = c1.taps;
+        s_fetch(n0); s_fetch(n1); s_fetch(n2);
+        const int trips = total / 3;
+        constexpr int FLUSH_TRIPS = 16;          // 48 items = a chain of <= 192 fp32 fmas per accumulator
+        for (int tb = 0; tb < trips; tb += FLUSH_TRIPS) {
+            const int te = tb + FLUSH_TRIPS < trips ? tb + FLUSH_TRIPS : trips;
+            for (int tr = tb; tr < te; ++tr) {
+                // the scalar table reads of a whole trip are issued together, one trip ahead of their use, into their
+                // own registers (copying a pending scalar load serialises the three fetches behind three waits)
+                c0 = n0; c1 = n1; c2 = n2;
+                s_fetch(n0); s_fetch(n1); s_fetch(n2);
+                v_issue(c0, v2); t2 = c0.taps;
+                mfma(v0, t0);
+                v_issue(c1, v0); t0 = c1.taps;
+                mfma(v1, t1);
+                v_issue(c2, v1); t1 = c2.taps;
+                mfma(v2, t2);
+            }
+            flush();
+        }
+        const int t = trips * 3;
+        if (t < total) mfma(v0, t0);
+        if (t + 1 < total) mfma(v1, t1);
+        flush();
+    }
+
+    const int p0 = pb * NP;
+    if (nw == 1) {
+        // single-wave workgroup: straight from registers, 16 bytes per lane
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            const int p = p0 + pl;
+            if (p >= d.n_pos) break;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = mt * 16 + kk * 4 + r;
+                    const int drow = d.dst_rows[g * (MT * 16) + row];
+                    if (drow < 0) continue;
+                    f32x4 s = {tot[pl][mt][0][r], tot[pl][mt][1][r], tot[pl][mt][2][r], tot[pl][mt][3][r]};
+                    if (d.bias) {
+                        const int bi = d.bias_idx[g * (MT * 16) + row];
+                        const float bv = bi >= 0 ? d.bias[bi] : 0.f;
+                        s += (f32x4){bv, bv, bv, bv};
+                    }
+                    if (d.flags & HMVAE_FLAG_LEAKY) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s[e] = s[e] > 0.f ? s[e] : s[e] * d.slope;
+                    }
+                    float* dp = d.dst + (size_t)(drow + p * d.dst_ts) * bp + (ct << 6) + (n << 2);
+                    if (d.flags & HMVAE_FLAG_ACCUM) s += *(const f32x4*)dp;
+                    *(f32x4*)dp = s;
+                }
+        }
+        return;
+    }
+    // K split over the waves: sum through LDS, one position at a time
+    float* redf = red + TABLE_INTS;
+    float* mine = redf + wave * (MT * 16 * 64);
+    const int rl = threadIdx.x >> 4;
+    const int cq = threadIdx.x & 15;
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+        const int p = p0 + pl;
+        if (p >= d.n_pos) break;               // uniform over the workgroup
+        if (pl > 0) __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4 v = {tot[pl][mt][0][r], tot[pl][mt][1][r], tot[pl][mt][2][r], tot[pl][mt][3][r]};
+                *(f32x4*)(mine + (mt * 16 + kk * 4 + r) * 64 + (n << 2)) = v;
+            }
+        __syncthreads();
+        for (int row = rl; row < MT * 16; row += (blockDim.x >> 4)) {
+            const int drow = d.dst_rows[g * (MT * 16) + row];
+            if (drow < 0) continue;
+            f32x4 s = *(const f32x4*)(redf + row * 64 + (cq << 2));
+            for (int w = 1; w < nw; ++w) s += *(const f32x4*)(redf + w * (MT * 16 * 64) + row * 64 + (cq << 2));
+            if (d.bias) {
+                const int bi = d.bias_idx[g * (MT * 16) + row];
+                const float bv = bi >= 0 ? d.bias[bi] : 0.f;
+                s += (f32x4){bv, bv, bv, bv};
+            }
+            if (d.flags & HMVAE_FLAG_LEAKY) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] = s[e] > 0.f ? s[e] : s[e] * d.slope;
+            }
+            float* dp = d.dst + (size_t)(drow + p * d.dst_ts) * bp + (ct << 6) + (cq << 2);
+            if (d.flags & HMVAE_FLAG_ACCUM) s += *(const f32x4*)dp;
+            *(f32x4*)dp = s;
+        }
+    }
+}
+
+template <int MT, int NP>
+static int launch2(const hmvae_gemm2_desc* d, hipStream_t s) {
+    const int per = (d->n_units + 7) / 8;
+    dim3 grid((unsigned)(per * 8)), block(64 * d->ksplit);
+    const size_t lds = TABLE_INTS * sizeof(int) + (d->ksplit > 1 ? (size_t)d->ksplit * MT * 16 * 64 * sizeof(float) : 0);
+    hipLaunchKernelGGL((gather_gemm2_kernel<MT, NP>), grid, block, lds, s, *d);
+    return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+}
+
+extern "C" int hmvae_gather_gemm_v2(const hmvae_gemm2_desc* desc, hmvae_stream_t stream) {
+    if (!desc || !desc->src || !desc->dst || !desc->wp || !desc->items || (desc->bias && !desc->bias_idx)) return HMVAE_ERR_ARG;
+    if (desc->bp <= 0 || (desc->bp & 63) || desc->n_groups <= 0 || desc->n_pos <= 0 || desc->kt <= 0 || desc->kt > 254)
+        return HMVAE_ERR_ARG;
+    if (desc->ksplit != 1 && desc->ksplit != 2 && desc->ksplit != 4) return HMVAE_ERR_ARG;
+    if (desc->max_items <= 0 || desc->max_items > MAX_ITEMS || desc->max_nc4 <= 0 || desc->max_nc4 > MAX_C4) return HMVAE_ERR_UNSUPPORTED;
+    if (desc->n_pblk != (desc->n_pos + desc->np - 1) / desc->np) return HMVAE_ERR_ARG;
+    if ((long long)desc->n_groups * desc->n_pblk * (desc->bp >> 6) != desc->n_units) return HMVAE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int key = desc->mt * 10 + desc->np;
+    switch (key) {
+        case 11: return launch2<1, 1>(desc, s);
+        case 12: return launch2<1, 2>(desc, s);
+        case 14: return launch2<1, 4>(desc, s);
+        case 21: return launch2<2, 1>(desc, s);
+        case 22: return launch2<2, 2>(desc, s);
+        case 31: return launch2<3, 1>(desc, s);
+        case 41: return launch2<4, 1>(desc, s);
+        default: return HMVAE_ERR_UNSUPPORTED;
+    }
+}

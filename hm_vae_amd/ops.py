@@ -14,6 +14,11 @@ from . import _lib
 from . import planner as P
 
 
+import os as _os
+
+USE_V2 = _os.environ.get("HMVAE_GEMM", "v2") != "v1"
+
+
 def pad_batch(b):
     return (int(b) + 63) // 64 * 64
 
@@ -49,6 +54,9 @@ class _Side:
         else:
             self.bias_idx = _dev(np.where(ri >= 0, bias_rows[np.maximum(ri, 0)], -1).astype(np.int32), device)
         p_off, p_len, flat = P.flatten_pairs(pairs)
+        self.pairs_host = pairs
+        self._items = {}
+        self.tune = None                      # (np, ksplit) override for experiments
         self.n_pos = len(pairs)
         self.p_off, self.p_len, self.pairs = _dev(p_off, device), _dev(p_len, device), _dev(flat, device)
         self.src_ts, self.dst_ts = int(src_ts), int(dst_ts)
@@ -64,7 +72,39 @@ class _Side:
                                           _lib.ptr(self.g_okoff), _lib.ptr(self.pair_ok), g.n_groups, g.mt, g.kt, rs, cs,
                                           ts, 0, _lib.stream()), "pack_weights")
 
+    def items_for(self, np_):
+        if np_ not in self._items:
+            pb_off, pb_len, items = P.build_items(self.pairs_host, np_)
+            self._items[np_] = (_dev(pb_off, self.device), _dev(pb_len, self.device), _dev(items, self.device), len(pb_off),
+                                int(pb_len.max()))
+        return self._items[np_]
+
+    def choose(self, bp):
+        if self.tune is not None:
+            return self.tune
+        g = self.g
+        return P.pick_np_ksplit(g.mt, g.n_groups, self.n_pos, bp // 64, float(g.g_nc4.mean()))
+
     def run(self, src, dst, bp, bias=None, flags=0, slope=0.2):
+        if USE_V2:
+            return self.run_v2(src, dst, bp, bias, flags, slope)
+        return self.run_v1(src, dst, bp, bias, flags, slope)
+
+    def run_v2(self, src, dst, bp, bias=None, flags=0, slope=0.2):
+        lib = _lib.load()
+        g = self.g
+        np_, ks = self.choose(bp)
+        pb_off, pb_len, items, n_pblk, max_items = self.items_for(np_)
+        n_units = g.n_groups * n_pblk * (int(bp) // 64)
+        d = _lib.Gemm2Desc(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(self.wp), _lib.ptr(bias), _lib.ptr(self.bias_idx),
+                           _lib.ptr(self.g_nc4), _lib.ptr(self.g_woff), _lib.ptr(self.g_choff), _lib.ptr(self.chan_rows),
+                           _lib.ptr(self.dst_rows), _lib.ptr(pb_off), _lib.ptr(pb_len), _lib.ptr(items), g.n_groups, g.mt,
+                           g.kt, self.n_pos, int(bp), np_, n_pblk, n_units, ks, max_items, int(g.g_nc4.max()), self.src_ts,
+                           self.dst_ts, int(flags),
+                           float(slope))
+        _lib.check(lib.hmvae_gather_gemm_v2(C.byref(d), _lib.stream()), "gather_gemm_v2")
+
+    def run_v1(self, src, dst, bp, bias=None, flags=0, slope=0.2):
         lib = _lib.load()
         g = self.g
         d = _lib.GemmDesc(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(self.wp), _lib.ptr(bias), _lib.ptr(self.bias_idx),

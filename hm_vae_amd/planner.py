@@ -103,6 +103,9 @@ def _merge_units(units, cap):
 
 def make_groups(joint_rows, joint_chans, kt, mt_choices=(1, 2, 3, 4)):
     """joint_rows[j]: dense row ids owned by block j; joint_chans[j]: dense channel ids block j reads."""
+    import os
+    if os.environ.get("HMVAE_MT"):
+        mt_choices = tuple(int(c) for c in os.environ["HMVAE_MT"].split(","))
     best = None
     row_chans = {}
     for rows, chans in zip(joint_rows, joint_chans):
@@ -205,3 +208,56 @@ def pick_split(n_tiles, k_chunks, target_blocks=1024, max_split=64):
     """Split of the (position, batch) reduction of the weight-gradient GEMM across workgroups."""
     s = max(1, min(max_split, -(-target_blocks // max(n_tiles, 1))))
     return int(max(1, min(s, max(1, k_chunks // 4))))
+
+
+def build_items(pairs, np_):
+    """Group consecutive output positions in blocks of np_ and merge their (q, tap) pairs by source position q.
+
+    Returns (pb_off, pb_len, items) with items as int32 pairs [q, taps]; taps packs one tap per owned position,
+    8 bits each, 0xff = unused.  A q that a position reads through two taps (reflection) yields two items.
+    """
+    n_pos = len(pairs)
+    pb_off, pb_len, flat = [], [], []
+    for p0 in range(0, n_pos, np_):
+        by_q = {}
+        for pl in range(np_):
+            if p0 + pl >= n_pos:
+                break
+            for q, tap in pairs[p0 + pl]:
+                by_q.setdefault(q, [[] for _ in range(np_)])[pl].append(tap)
+        pb_off.append(len(flat) // 2)
+        cnt = 0
+        for q in sorted(by_q):
+            lists = by_q[q]
+            while any(lists):
+                word = 0
+                for pl in range(np_):
+                    tap = lists[pl].pop(0) if lists[pl] else 0xff
+                    word |= (tap & 0xff) << (8 * pl)
+                for pl in range(np_, 4):
+                    word |= 0xff << (8 * pl)
+                if word >= 2 ** 31:
+                    word -= 2 ** 32
+                flat.extend((q, word))
+                cnt += 1
+        pb_len.append(cnt)
+    if not flat:
+        flat = [0, -1]
+    return (np.asarray(pb_off, dtype=np.int32), np.asarray(pb_len, dtype=np.int32), np.asarray(flat, dtype=np.int32))
+
+
+def pick_np_ksplit(mt, n_groups, n_pos, n_col_tiles, avg_nc4, target_waves=2048):
+    """Positions per wave and K split over the waves of a workgroup.
+
+    Measured on MI355X (tools/sweep_gemm.py, B=256): one position per wave with the reduction split over 4 waves wins
+    on every layer of the len64 model — the kernel is bound by L2->L1 operand bandwidth per CU, and more resident
+    waves (not more registers per wave) is what keeps loads in flight.  K is only left unsplit when a group has too
+    few 4-channel steps to give every wave a pipelined loop.
+    """
+    if avg_nc4 >= 8:
+        ks = 4
+    elif avg_nc4 >= 4:
+        ks = 2
+    else:
+        ks = 1
+    return 1, ks

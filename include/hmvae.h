@@ -70,6 +70,34 @@ typedef struct {
 
 int hmvae_gather_gemm(const hmvae_gemm_desc* desc, hmvae_stream_t stream);
 
+/* Second-generation gather-GEMM: a wave owns `np` consecutive output positions and walks a per-position-block
+ * list of "items" (source position q + one tap per owned position, 0xff = this position does not read q), so one
+ * activation load feeds up to np MFMA groups.  Same maths and weight layout as hmvae_gather_gemm.
+ * Work unit = (group, position block, 64-column tile); units are dealt to XCDs in contiguous group-major ranges. */
+typedef struct {
+    const float* src;
+    float* dst;
+    const float* wp;
+    const float* bias;
+    const int32_t* bias_idx;
+    const int32_t* g_nc4;
+    const int32_t* g_woff;
+    const int32_t* g_choff;
+    const int32_t* chan_rows;
+    const int32_t* dst_rows;
+    const int32_t* pb_off;   /* [n_pblk] first item of the block */
+    const int32_t* pb_len;   /* [n_pblk] */
+    const int32_t* items;    /* pairs of int32: q, taps packed 8 bits per owned position */
+    int32_t n_groups, mt, kt, n_pos, bp;
+    int32_t np, n_pblk, n_units, ksplit;
+    int32_t max_items, max_nc4;   /* largest pb_len / g_nc4 (the kernel stages both tables in LDS: <= 256 / <= 512) */
+    int32_t src_ts, dst_ts;
+    int32_t flags;
+    float slope;
+} hmvae_gemm2_desc;
+
+int hmvae_gather_gemm_v2(const hmvae_gemm2_desc* desc, hmvae_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Weight-gradient GEMM (autograd of skeleton.py:95-105 / nn.Linear w.r.t. weight), split over the
  * (position, batch) reduction into `n_split` slabs, then a deterministic reduce into the dense grad.

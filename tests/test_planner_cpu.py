@@ -130,3 +130,33 @@ def test_grouping_efficiency_len64():
         gs = planner.make_groups(rows, chans, 15)
         eff = gs.useful() / (gs.mfma_cost())
         assert eff > 0.55, (lvl, cin, cout, gs.mt, eff)
+
+
+@pytest.mark.parametrize("np_", [1, 2, 4])
+@pytest.mark.parametrize("geom", [(64, 15, 2, "reflect"), (8, 15, 1, "reflect"), (8, 3, 2, "reflect"), (6, 5, 1, "zeros"),
+                                  (2, 3, 1, "reflect")])
+def test_items_expand_to_pairs(np_, geom):
+    """The v2 kernel's item lists (source position + one tap per owned output position) must enumerate exactly
+    the (q, tap) pairs of every output position, forward and backward-data."""
+    t_in, kt, stride, mode = geom
+    pad = (kt - 1) // 2
+    t_out = (t_in + 2 * pad - kt) // stride + 1
+    for pairs in (planner.conv_pairs_fwd(t_in, t_out, kt, stride, pad, mode),
+                  planner.conv_pairs_bwd(t_in, t_out, kt, stride, pad, mode)):
+        pb_off, pb_len, items = planner.build_items(pairs, np_)
+        items = items.reshape(-1, 2)
+        got = [[] for _ in pairs]
+        for pb in range(len(pb_off)):
+            for k in range(pb_off[pb], pb_off[pb] + pb_len[pb]):
+                q, word = int(items[k, 0]), int(items[k, 1]) & 0xffffffff
+                for pl in range(4):
+                    tap = (word >> (8 * pl)) & 0xff
+                    if tap != 0xff:
+                        assert pl < np_ and pb * np_ + pl < len(pairs)
+                        got[pb * np_ + pl].append((q, tap))
+        for a, b in zip(got, pairs):
+            assert sorted(a) == sorted(b)
+    # heuristic returns a supported (np, ksplit)
+    for mt in (1, 2, 3, 4):
+        np2, ks = planner.pick_np_ksplit(mt, 7, t_out, 4, 20.0)
+        assert np2 * mt <= 4 and ks in (1, 2, 4) and np2 <= max(1, t_out)

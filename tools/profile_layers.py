@@ -1,0 +1,44 @@
+"""Dev tool (GPU box): per-layer timing of every MFMA launch of the engine at B=256 (HIP events, 20 reps)."""
+import sys, os
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from hm_vae_amd.trainer_motion_vae import Trainer
+from hm_vae_amd.utils_common import get_config
+from hm_vae_amd import ops
+cfg = get_config(os.path.join(ROOT, "configs", "len64_no_aug_hm_vae.yaml"))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+tr = Trainer(cfg); tr.cuda()
+eng = tr.model.engine(); w = eng.workspace(B); bp = w["bp"]
+eng.pack_weights()
+dev = eng.device
+def timeit(fn, reps=20):
+    for _ in range(3): fn()
+    evs = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); evs.append((a, b))
+    torch.cuda.synchronize()
+    return sorted(x.elapsed_time(y) for x, y in evs)[len(evs)//2] * 1e3
+L = eng.p.L
+names = ["enc%d" % i for i in range(L)] + ["dec%d" % i for i in range(L)]
+convs = eng.enc_conv + eng.dec_conv
+tot = {"fwd": 0, "bwd": 0, "wg": 0}
+print("B=%d bp=%d" % (B, bp))
+for name, op in zip(names, convs):
+    cout, cin, kt = op.w_shape
+    x = torch.randn(cin * op.t_in, bp, device=dev); y = torch.empty(cout * op.t_out + 400000, bp, device=dev)
+    dy = torch.randn(y.shape[0], bp, device=dev); dx = torch.empty_like(x); dw = torch.zeros(cout, cin, kt, device=dev)
+    slab = torch.empty(op.slab_floats(bp), device=dev)
+    useful = 2.0 * op.useful_macs_per_col * bp
+    gf, gb = op.fwd.g, (op.bwd.g if op.bwd else None)
+    t_f = timeit(lambda: op.forward(x, y, bp))
+    line = "%s fwd: mt%d groups %3d pos %2d blocks %5d  %7.1f us %5.1f TF (eff) " % (name, gf.mt, gf.n_groups, op.fwd.n_pos, gf.n_groups*op.fwd.n_pos*(bp//64), t_f, useful/t_f/1e6)
+    tot["fwd"] += t_f
+    if op.bwd:
+        t_b = timeit(lambda: op.backward_data(dy, dx, bp)); tot["bwd"] += t_b
+        line += "| bwd: mt%d groups %3d pos %2d blocks %5d %7.1f us %5.1f TF " % (gb.mt, gb.n_groups, op.bwd.n_pos, gb.n_groups*op.bwd.n_pos*(bp//64), t_b, useful/t_b/1e6)
+    t_w = timeit(lambda: op.backward_weight(dy, x, dw, bp, slab)); tot["wg"] += t_w
+    line += "| wgrad: tiles %4d split %2d %7.1f us %5.1f TF" % (op.n_tiles, op.n_split(bp), t_w, useful/t_w/1e6)
+    print(line)
+print("totals us:", tot, "sum", sum(tot.values()))
