@@ -227,19 +227,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
             tot[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 
-    const int nb16 = bp >> 4;
-    const long long total = (long long)d.t_dst * nb16;
+    // Reduction chunks: one position t x 32 batch columns.  Lane (n, kk) loads the 32 contiguous bytes
+    // [b0 + 8kk, b0 + 8kk + 8) of its row, so the 4 kk-lanes of a row cover one full 128-byte line, and MFMA k-step j
+    // (0..7) uses batch element 8kk + j on both operands.  Chunks are numbered with t fastest, so the four waves of
+    // a workgroup work on neighbouring positions of the same batch block at the same time and share most of their
+    // activation rows (a row read for tap k at position t is the row for tap k-stride at t+1) in L1.
+    const int nb32 = bp >> 5;
+    const int T = d.t_dst;
+    const long long total = (long long)T * nb32;
     const int lo = (int)(total * sp / d.n_split);
     const int hi = (int)(total * (sp + 1) / d.n_split);
-    const float* __restrict__ dzp = d.dz + (kk << 2);
-    const float* __restrict__ xp = d.x + (kk << 2);
-    int since_flush = 0;
-    for (int chunk = lo + wave; chunk < hi; chunk += 4) {
-        const int t = chunk / nb16;
-        const int b0 = (chunk - t * nb16) << 4;
-        f32x4 a[MT], b[4];
+    const float* __restrict__ dzp = d.dz + (kk << 3);
+    const float* __restrict__ xp = d.x + (kk << 3);
+    struct Ops {
+        f32x4 a[MT][2];
+        f32x4 b[4][2];
+    };
+    auto load = [&](Ops& o, int chunk) {
+        const int bb = chunk / T;
+        const int t = chunk - bb * T;
+        const int b0 = bb << 5;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(dzp + (size_t)(dzrow[mt] + t * d.dz_ts) * bp + b0);
+        for (int mt = 0; mt < MT; ++mt) {
+            const float* p = dzp + (size_t)(dzrow[mt] + t * d.dz_ts) * bp + b0;
+            o.a[mt][0] = *(const f32x4*)p;
+            o.a[mt][1] = *(const f32x4*)(p + 4);
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             int u = t * d.stride + tap[nt] - d.pad;
@@ -251,30 +264,60 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
                 ok = (u >= 0) && (u < d.t_src);
                 if (!ok) u = 0;
             }
-            f32x4 v = *(const f32x4*)(xp + (size_t)(xrow[nt] + u * d.x_ts) * bp + b0);
-            b[nt] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* p = xp + (size_t)(xrow[nt] + u * d.x_ts) * bp + b0;
+            const f32x4 v0 = *(const f32x4*)p, v1 = *(const f32x4*)(p + 4);
+            o.b[nt][0] = ok ? v0 : (f32x4){0.f, 0.f, 0.f, 0.f};
+            o.b[nt][1] = ok ? v1 : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+    };
+    auto fma = [&](const Ops& o) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(a[mt][j], b[nt][j], acc[mt][nt]);
-        if (++since_flush == 16) {
-            since_flush = 0;
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(o.a[mt][h][j], o.b[nt][h][j], acc[mt][nt]);
+    };
+    auto flush = [&]() {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    tot[mt][nt] += acc[mt][nt];
-                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                tot[mt][nt] += acc[mt][nt];
+                acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+    };
+    // this wave's chunks: lo + wave, lo + wave + 4, ...   (software pipelined two deep over two static register sets)
+    const int first = lo + wave;
+    const int n_mine = first < hi ? (hi - first + 3) >> 2 : 0;
+    if (n_mine > 0) {
+        Ops o0, o1;
+        load(o0, first);
+        const int last = first + 4 * (n_mine - 1);
+        const int pairs = n_mine >> 1;
+        constexpr int FLUSH_PAIRS = 4;           // 8 chunks = 64 k-steps = a chain of 256 fp32 fmas
+        int c = first;
+        for (int pb = 0; pb < pairs; pb += FLUSH_PAIRS) {
+            const int pe = pb + FLUSH_PAIRS < pairs ? pb + FLUSH_PAIRS : pairs;
+            for (int pi = pb; pi < pe; ++pi) {
+                load(o1, c + 4);
+                fma(o0);
+                const int nxt = c + 8 <= last ? c + 8 : last;      // clamped over-fetch at the tail
+                load(o0, nxt);
+                fma(o1);
+                c += 8;
+            }
+            flush();
         }
+        if (n_mine & 1) fma(o0);
+        flush();
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] += tot[mt][nt];
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = tot[mt][nt];
     // acc[mt][nt][r] is row mt*16 + kk*4 + r, column nt*16 + n
     float* mine = red + wave * (MT * 16 * 64);
 #pragma unroll

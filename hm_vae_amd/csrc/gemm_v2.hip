@@ -25,45 +25,62 @@ struct VStage {          // operands of one item, in flight between its loads an
     f32x4 b;
     float a[NP][MT];
 };
-struct SStage {          // the item's table entries, read from the LDS copies of the tables
-    int q, taps, c4;
-    int row;             // this lane's source row base (channel kk of the 4-channel step)
+struct SStage {          // the item's table entries, read from the LDS copies of the tables (byte offsets)
+    unsigned boff;       // activation: (row base of this lane's channel + q*src_ts) * bp * 4
+    unsigned aoff;       // weights:    (c4*kt + tap) * MT*64*4
+    int taps;
 };
 
-template <int MT, int NP>
+template <int MT, int NP, int DEPTH>
 __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
     extern __shared__ __attribute__((aligned(16))) float red[];
-    const int nw = blockDim.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int wpos = d.wpos;                         // 1: waves split K;  4: waves take 4 neighbouring position blocks
+    const int nw = wpos > 1 ? 1 : nwaves;            // K-split factor
     const int per = (d.n_units + 7) >> 3;
     const int u = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per || u >= d.n_units) return;
     const int n_ct = d.bp >> 6;
     const int ct = u % n_ct;
     const int r0 = u / n_ct;
-    const int pb = r0 % d.n_pblk;
-    const int g = r0 / d.n_pblk;
+    const int n_pq = (d.n_pblk + wpos - 1) / wpos;
+    const int pq = r0 % n_pq;
+    const int g = r0 / n_pq;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: keeps the K loop uniform
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // scalar: keeps the K loop uniform
+    const int wave = wpos > 1 ? 0 : wid;             // index inside the K split
+    const int pb = wpos > 1 ? pq * wpos + wid : pq;  // this wave's position block
+    const bool live = pb < d.n_pblk;
     const int kk = lane >> 4;
     const int n = lane & 15;
 
     const int nc4 = d.g_nc4[g];
     const int choff = d.g_choff[g];
-    const int nitems = d.pb_len[pb];
+    const int nitems = live ? d.pb_len[pb] : 0;
     // tables -> LDS (uniform/broadcast ds_reads in the loop instead of scalar-memory loads with their waits)
-    int* lds_items = (int*)red;                       // [nitems][2]
-    int* lds_rows = lds_items + 2 * MAX_ITEMS;        // [nc4*4]
+    int* lds_rows = (int*)red;                                                   // [nc4*4], shared by the workgroup
+    int* lds_items = lds_rows + 4 * MAX_C4 + (wpos > 1 ? wid * 2 * MAX_ITEMS : 0);   // [nitems][2] (per wave if wpos>1)
     {
-        const int* gi = d.items + 2 * d.pb_off[pb];
-        for (int i = threadIdx.x; i < 2 * nitems; i += blockDim.x) lds_items[i] = gi[i];
+        // items become {q*src_ts*bp*4, taps}; rows become row*bp*4: the loop then needs one add per operand address
+        if (wpos > 1) {
+            if (live) {
+                const int* gi = d.items + 2 * d.pb_off[pb];
+                for (int i = lane; i < 2 * nitems; i += 64) lds_items[i] = (i & 1) ? gi[i] : gi[i] * d.src_ts * d.bp * 4;
+            }
+        } else {
+            const int* gi = d.items + 2 * d.pb_off[pb];
+            for (int i = threadIdx.x; i < 2 * nitems; i += blockDim.x)
+                lds_items[i] = (i & 1) ? gi[i] : gi[i] * d.src_ts * d.bp * 4;
+        }
         const int* gr = d.chan_rows + choff;
-        for (int i = threadIdx.x; i < 4 * nc4; i += blockDim.x) lds_rows[i] = gr[i];
+        for (int i = threadIdx.x; i < 4 * nc4; i += blockDim.x) lds_rows[i] = gr[i] * d.bp * 4;
     }
     __syncthreads();
-    const float* __restrict__ wg = d.wp + d.g_woff[g] + lane;
-    const float* __restrict__ srcc = d.src + (ct << 6) + (n << 2);
+    const char* __restrict__ wbase = (const char*)(d.wp + d.g_woff[g]);        // uniform
+    const char* __restrict__ sbase = (const char*)d.src;                          // uniform
+    const unsigned lane_a = (unsigned)lane * 4u;                                  // this lane's byte offset in an A fragment
+    const unsigned lane_b = (unsigned)((ct << 6) + (n << 2)) * 4u;                // ... in a 64-column batch tile
     const int bp = d.bp;
-    const int src_ts = d.src_ts;
     const int kt = d.kt;
 
     f32x4 acc[NP][MT][4], tot[NP][MT][4];
@@ -89,10 +106,9 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
         int lc4 = wave, lit = 0;
         auto s_fetch = [&](SStage& s) {
             const int2 it = *(const int2*)(lds_items + 2 * lit);
-            s.q = it.x;
             s.taps = it.y;
-            s.c4 = lc4;
-            s.row = lds_rows[lc4 * 4 + kk];
+            s.boff = (unsigned)lds_rows[lc4 * 4 + kk] + (unsigned)it.x + lane_b;
+            s.aoff = (unsigned)(lc4 * kt + (it.y & 0xff)) * (unsigned)(MT * 256) + lane_a;
             const int nl = lit + 1;
             const bool wrap = nl == nitems;
             const int nc = wrap ? lc4 + nw : lc4;
@@ -101,15 +117,10 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
             lc4 = ok ? nc : lc4;
         };
         auto v_issue = [&](const SStage& s, VStage<MT, NP>& v) {
-            v.b = *(const f32x4*)(srcc + (size_t)(s.row + s.q * src_ts) * bp);
+            static_assert(NP == 1, "one output position per wave (register blocking over positions did not pay)");
+            v.b = *(const f32x4*)(sbase + s.boff);
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
-                int tap = (s.taps >> (8 * pl)) & 0xff;
-                tap = tap == 0xff ? 0 : tap;
-                const float* wc = wg + (size_t)(s.c4 * kt + tap) * (MT * 64);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) v.a[pl][mt] = wc[mt * 64];
-            }
+            for (int mt = 0; mt < MT; ++mt) v.a[0][mt] = *(const float*)(wbase + s.aoff + mt * 256);
         };
         auto mfma = [&](const VStage<MT, NP>& v, int taps) {
 #pragma unroll
@@ -133,33 +144,45 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
                         acc[pl][mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
         };
-        VStage<MT, NP> v0, v1, v2;
-        SStage c0, c1, c2, n0, n1, n2;
-        int t0, t1, t2;
-        s_fetch(c0); v_issue(c0, v0); t0 = c0.taps;
-        s_fetch(c1); v_issue(c1, v1); t1 = c1.taps;
-        s_fetch(n0); s_fetch(n1); s_fetch(n2);
-        const int trips = total / 3;
-        constexpr int FLUSH_TRIPS = 16;          // 48 items = a chain of <= 192 fp32 fmas per accumulator
+        // Ring of DEPTH+1 operand sets with STATIC roles (the trip body is fully unrolled): set u is consumed by the
+        // MFMAs of sub-step u while set (u+DEPTH)%(DEPTH+1) is being filled for the item DEPTH ahead.  The table
+        // entries of a whole trip are read from LDS one trip ahead into their own registers.
+        constexpr int R = DEPTH + 1;
+        VStage<MT, NP> v[R];
+        SStage c[R], nx[R];
+        int tp[R];
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            s_fetch(c[u]);
+            v_issue(c[u], v[u]);
+            tp[u] = c[u].taps;
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) s_fetch(nx[u]);
+        const int trips = total / R;
+        constexpr int FLUSH_ITEMS = 48;          // a chain of <= 192 fp32 fmas per accumulator between folds
+        constexpr int FLUSH_TRIPS = (FLUSH_ITEMS + R - 1) / R;
         for (int tb = 0; tb < trips; tb += FLUSH_TRIPS) {
             const int te = tb + FLUSH_TRIPS < trips ? tb + FLUSH_TRIPS : trips;
             for (int tr = tb; tr < te; ++tr) {
-                // the scalar table reads of a whole trip are issued together, one trip ahead of their use, into their
-                // own registers (copying a pending scalar load serialises the three fetches behind three waits)
-                c0 = n0; c1 = n1; c2 = n2;
-                s_fetch(n0); s_fetch(n1); s_fetch(n2);
-                v_issue(c0, v2); t2 = c0.taps;
-                mfma(v0, t0);
-                v_issue(c1, v0); t0 = c1.taps;
-                mfma(v1, t1);
-                v_issue(c2, v1); t1 = c2.taps;
-                mfma(v2, t2);
+#pragma unroll
+                for (int u = 0; u < R; ++u) c[u] = nx[u];
+#pragma unroll
+                for (int u = 0; u < R; ++u) s_fetch(nx[u]);
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    const int w = (u + DEPTH) % R;      // == u-1 (mod R): the set drained by the previous sub-step
+                    v_issue(c[u], v[w]);
+                    tp[w] = c[u].taps;
+                    mfma(v[u], tp[u]);
+                }
             }
             flush();
         }
-        const int t = trips * 3;
-        if (t < total) mfma(v0, t0);
-        if (t + 1 < total) mfma(v1, t1);
+        // tail: the next (total % R) items are already in flight in sets 0..
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u)
+            if (trips * R + u < total) mfma(v[u], tp[u]);
         flush();
     }
 
@@ -195,7 +218,7 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
         return;
     }
     // K split over the waves: sum through LDS, one position at a time
-    float* redf = red + TABLE_INTS;
+    float* redf = red + TABLE_INTS + 3 * 2 * MAX_ITEMS;
     float* mine = redf + wave * (MT * 16 * 64);
     const int rl = threadIdx.x >> 4;
     const int cq = threadIdx.x & 15;
@@ -236,9 +259,12 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
 template <int MT, int NP>
 static int launch2(const hmvae_gemm2_desc* d, hipStream_t s) {
     const int per = (d->n_units + 7) / 8;
-    dim3 grid((unsigned)(per * 8)), block(64 * d->ksplit);
-    const size_t lds = TABLE_INTS * sizeof(int) + (d->ksplit > 1 ? (size_t)d->ksplit * MT * 16 * 64 * sizeof(float) : 0);
-    hipLaunchKernelGGL((gather_gemm2_kernel<MT, NP>), grid, block, lds, s, *d);
+    dim3 grid((unsigned)(per * 8)), block(64 * (d->wpos > 1 ? d->wpos : d->ksplit));
+    const size_t lds = (TABLE_INTS + 3 * 2 * MAX_ITEMS) * sizeof(int) +
+                       (d->ksplit > 1 ? (size_t)d->ksplit * MT * 16 * 64 * sizeof(float) : 0);
+    // prefetch distance in items: short MFMA groups (one 16-row tile) need more loads in flight per wave
+    constexpr int DEPTH = (MT * NP == 1) ? 5 : (MT * NP == 2 ? 3 : 2);
+    hipLaunchKernelGGL((gather_gemm2_kernel<MT, NP, DEPTH>), grid, block, lds, s, *d);
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }
 
@@ -249,15 +275,15 @@ extern "C" int hmvae_gather_gemm_v2(const hmvae_gemm2_desc* desc, hmvae_stream_t
     if (desc->ksplit != 1 && desc->ksplit != 2 && desc->ksplit != 4) return HMVAE_ERR_ARG;
     if (desc->max_items <= 0 || desc->max_items > MAX_ITEMS || desc->max_nc4 <= 0 || desc->max_nc4 > MAX_C4) return HMVAE_ERR_UNSUPPORTED;
     if (desc->n_pblk != (desc->n_pos + desc->np - 1) / desc->np) return HMVAE_ERR_ARG;
-    if ((long long)desc->n_groups * desc->n_pblk * (desc->bp >> 6) != desc->n_units) return HMVAE_ERR_ARG;
+    if (desc->wpos != 1 && desc->wpos != 4) return HMVAE_ERR_ARG;
+    if (desc->wpos > 1 && desc->ksplit != 1) return HMVAE_ERR_ARG;
+    if ((long long)desc->n_groups * ((desc->n_pblk + desc->wpos - 1) / desc->wpos) * (desc->bp >> 6) != desc->n_units)
+        return HMVAE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int key = desc->mt * 10 + desc->np;
     switch (key) {
         case 11: return launch2<1, 1>(desc, s);
-        case 12: return launch2<1, 2>(desc, s);
-        case 14: return launch2<1, 4>(desc, s);
         case 21: return launch2<2, 1>(desc, s);
-        case 22: return launch2<2, 2>(desc, s);
         case 31: return launch2<3, 1>(desc, s);
         case 41: return launch2<4, 1>(desc, s);
         default: return HMVAE_ERR_UNSUPPORTED;

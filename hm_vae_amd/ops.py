@@ -93,13 +93,15 @@ class _Side:
     def run_v2(self, src, dst, bp, bias=None, flags=0, slope=0.2):
         lib = _lib.load()
         g = self.g
-        np_, ks = self.choose(bp)
+        ch = self.choose(bp)
+        np_, ks = ch[0], ch[1]
+        wpos = ch[2] if len(ch) > 2 else 1
         pb_off, pb_len, items, n_pblk, max_items = self.items_for(np_)
-        n_units = g.n_groups * n_pblk * (int(bp) // 64)
+        n_units = g.n_groups * (-(-n_pblk // wpos)) * (int(bp) // 64)
         d = _lib.Gemm2Desc(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(self.wp), _lib.ptr(bias), _lib.ptr(self.bias_idx),
                            _lib.ptr(self.g_nc4), _lib.ptr(self.g_woff), _lib.ptr(self.g_choff), _lib.ptr(self.chan_rows),
                            _lib.ptr(self.dst_rows), _lib.ptr(pb_off), _lib.ptr(pb_len), _lib.ptr(items), g.n_groups, g.mt,
-                           g.kt, self.n_pos, int(bp), np_, n_pblk, n_units, ks, max_items, int(g.g_nc4.max()), self.src_ts,
+                           g.kt, self.n_pos, int(bp), np_, n_pblk, n_units, ks, wpos, max_items, int(g.g_nc4.max()), self.src_ts,
                            self.dst_ts, int(flags),
                            float(slope))
         _lib.check(lib.hmvae_gather_gemm_v2(C.byref(d), _lib.stream()), "gather_gemm_v2")
@@ -164,7 +166,7 @@ class MaskedGemm:
         self.bwd.run(dy, dx, bp, None, _lib.FLAG_ACCUM if accumulate else 0)
 
     def n_split(self, bp):
-        return P.pick_split(self.n_tiles, self.geom["t_dst"] * (bp // 16))
+        return P.pick_split(self.n_tiles, self.geom["t_dst"] * (bp // 32))
 
     def slab_floats(self, bp):
         return self.n_split(bp) * self.n_tiles * self.fwd.g.mt * 16 * 64

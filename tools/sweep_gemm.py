@@ -43,6 +43,13 @@ for name, op in zip(names, convs):
                 err = float((out - ref).abs().max() / ref.abs().max())
                 t = timeit(lambda: side.run_v2(src, out, bp))
                 res.append((t, np_, ks, err))
+        for wp in (4,):
+            side.tune = (1, 1, wp)
+            out.zero_()
+            side.run_v2(src, out, bp)
+            err = float((out - ref).abs().max() / ref.abs().max())
+            t = timeit(lambda: side.run_v2(src, out, bp))
+            res.append((t, 1, 10 + wp, err))
         side.tune = None
         auto = side.choose(bp)
         res.sort()
