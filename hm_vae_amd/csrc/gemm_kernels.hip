@@ -184,9 +184,11 @@ extern "C" int hmvae_gather_gemm(const hmvae_gemm_desc* desc, hmvae_stream_t str
 // K permutation: MFMA k-step j of a 16-batch block uses batch elements {4*kk + j}, so each lane feeds
 // four k-steps from one 16-byte load on both operands.
 // ------------------------------------------------------------------------------------------------
-template <int MT>
+template <int MT, bool ZP>
 __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
-    __shared__ __attribute__((aligned(16))) float red[4 * MT * 16 * 64];
+    // LDS: first the per-position activation offset table (during the reduction loop), then the cross-wave sums
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    unsigned* xtab = (unsigned*)red;                  // [t_dst][64]: byte offset of column c's activation row at position t
     const int tile = blockIdx.x % d.n_tiles;
     const int sp = blockIdx.x / d.n_tiles;
     const int g = d.tile_g[tile];
@@ -198,26 +200,45 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
     const int bp = d.bp;
     const int ncols = d.g_ncols[g];
     const int choff = d.g_choff[g];
+    const int T = d.t_dst;
 
-    int dzrow[MT];
+    // table: column c = threadIdx & 63 of this tile, positions t = wave, wave+4, ...   (all address arithmetic that
+    // depends on (t, tap) happens here, once; the loop only adds a scalar base — fp32 MFMA shares the SIMD's fp32
+    // datapath with ordinary vector instructions, so loop VALU work is time taken from the matrix pipe)
+    {
+        const int c = threadIdx.x & 63;
+        const int col = col0 + c;
+        int xr, tp;
+        if (col < ncols) {
+            const int ch = col / d.kt;
+            tp = col - ch * d.kt;
+            xr = d.chan_rows[choff + ch];
+        } else {
+            tp = 0;
+            xr = d.chan_rows[choff];
+        }
+        for (int t = threadIdx.x >> 6; t < T; t += 4) {
+            int u = t * d.stride + tp - d.pad;
+            unsigned v;
+            if (d.pad_mode == HMVAE_PAD_REFLECT) {
+                if (u < 0) u = -u;
+                if (u >= d.t_src) u = 2 * (d.t_src - 1) - u;
+                v = (unsigned)(xr + u * d.x_ts) * (unsigned)bp * 4u;
+            } else {
+                v = (u >= 0 && u < d.t_src) ? (unsigned)(xr + u * d.x_ts) * (unsigned)bp * 4u : 0xffffffffu;
+            }
+            xtab[t * 64 + c] = v;
+        }
+    }
+    unsigned rowbyte[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int r = d.dz_rows[g * (MT * 16) + mt * 16 + n];
-        dzrow[mt] = r < 0 ? 0 : r;
+        rowbyte[mt] = (unsigned)(r < 0 ? 0 : r) * (unsigned)bp * 4u + (unsigned)kk * 32u;
     }
-    int xrow[4], tap[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int col = col0 + nt * 16 + n;
-        if (col < ncols) {
-            const int c = col / d.kt;
-            tap[nt] = col - c * d.kt;
-            xrow[nt] = d.chan_rows[choff + c];
-        } else {
-            tap[nt] = 0;
-            xrow[nt] = d.chan_rows[choff];
-        }
-    }
+    const unsigned kk32 = (unsigned)kk * 32u;
+    __syncthreads();
+
     f32x4 acc[MT][4], tot[MT][4];          // two-level accumulation, see gather_gemm_kernel
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -230,44 +251,42 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
     // Reduction chunks: one position t x 32 batch columns.  Lane (n, kk) loads the 32 contiguous bytes
     // [b0 + 8kk, b0 + 8kk + 8) of its row, so the 4 kk-lanes of a row cover one full 128-byte line, and MFMA k-step j
     // (0..7) uses batch element 8kk + j on both operands.  Chunks are numbered with t fastest, so the four waves of
-    // a workgroup work on neighbouring positions of the same batch block at the same time and share most of their
-    // activation rows (a row read for tap k at position t is the row for tap k-stride at t+1) in L1.
+    // a workgroup work on neighbouring positions of the same batch block at the same time.
     const int nb32 = bp >> 5;
-    const int T = d.t_dst;
     const long long total = (long long)T * nb32;
     const int lo = (int)(total * sp / d.n_split);
     const int hi = (int)(total * (sp + 1) / d.n_split);
-    const float* __restrict__ dzp = d.dz + (kk << 3);
-    const float* __restrict__ xp = d.x + (kk << 3);
+    const char* __restrict__ dzb = (const char*)d.dz;
+    const char* __restrict__ xb = (const char*)d.x;
+    const unsigned dz_tstep = (unsigned)d.dz_ts * (unsigned)bp * 4u;
     struct Ops {
         f32x4 a[MT][2];
         f32x4 b[4][2];
     };
     auto load = [&](Ops& o, int chunk) {
-        const int bb = chunk / T;
+        const int bb = chunk / T;            // scalar
         const int t = chunk - bb * T;
-        const int b0 = bb << 5;
+        const char* dzs = dzb + (size_t)t * dz_tstep + (size_t)(bb << 7);      // uniform base for this chunk
+        const char* xs = xb + (size_t)(bb << 7);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const float* p = dzp + (size_t)(dzrow[mt] + t * d.dz_ts) * bp + b0;
-            o.a[mt][0] = *(const f32x4*)p;
-            o.a[mt][1] = *(const f32x4*)(p + 4);
+            o.a[mt][0] = *(const f32x4*)(dzs + rowbyte[mt]);
+            o.a[mt][1] = *(const f32x4*)(dzs + rowbyte[mt] + 16);
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            int u = t * d.stride + tap[nt] - d.pad;
-            bool ok = true;
-            if (d.pad_mode == HMVAE_PAD_REFLECT) {
-                if (u < 0) u = -u;
-                if (u >= d.t_src) u = 2 * (d.t_src - 1) - u;
+            const unsigned e = xtab[t * 64 + nt * 16 + n];
+            if (ZP) {
+                const bool ok = e != 0xffffffffu;
+                const unsigned off = (ok ? e : 0u) + kk32;
+                const f32x4 v0 = *(const f32x4*)(xs + off), v1 = *(const f32x4*)(xs + off + 16);
+                o.b[nt][0] = ok ? v0 : (f32x4){0.f, 0.f, 0.f, 0.f};
+                o.b[nt][1] = ok ? v1 : (f32x4){0.f, 0.f, 0.f, 0.f};
             } else {
-                ok = (u >= 0) && (u < d.t_src);
-                if (!ok) u = 0;
+                const unsigned off = e + kk32;
+                o.b[nt][0] = *(const f32x4*)(xs + off);
+                o.b[nt][1] = *(const f32x4*)(xs + off + 16);
             }
-            const float* p = xp + (size_t)(xrow[nt] + u * d.x_ts) * bp + b0;
-            const f32x4 v0 = *(const f32x4*)p, v1 = *(const f32x4*)(p + 4);
-            o.b[nt][0] = ok ? v0 : (f32x4){0.f, 0.f, 0.f, 0.f};
-            o.b[nt][1] = ok ? v1 : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     auto fma = [&](const Ops& o) {
@@ -314,18 +333,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
         if (n_mine & 1) fma(o0);
         flush();
     }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = tot[mt][nt];
-    // acc[mt][nt][r] is row mt*16 + kk*4 + r, column nt*16 + n
+    __syncthreads();                        // everyone is done with xtab: the LDS becomes the reduction buffer
+    // tot[mt][nt][r] is row mt*16 + kk*4 + r, column nt*16 + n
     float* mine = red + wave * (MT * 16 * 64);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mine[(mt * 16 + kk * 4 + r) * 64 + nt * 16 + n] = acc[mt][nt][r];
+            for (int r = 0; r < 4; ++r) mine[(mt * 16 + kk * 4 + r) * 64 + nt * 16 + n] = tot[mt][nt][r];
     __syncthreads();
     const int rl = threadIdx.x >> 4;
     const int cq = threadIdx.x & 15;
@@ -340,19 +356,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
     }
 }
 
+template <int MT>
+static void launch_wgrad(const hmvae_wgrad_desc* d, dim3 grid, hipStream_t s) {
+    size_t lds = (size_t)4 * MT * 16 * 64 * sizeof(float);
+    const size_t tab = (size_t)d->t_dst * 64 * sizeof(unsigned);
+    if (tab > lds) lds = tab;
+    if (d->pad_mode == HMVAE_PAD_ZEROS) hipLaunchKernelGGL((wgrad_kernel<MT, true>), grid, dim3(256), lds, s, *d);
+    else hipLaunchKernelGGL((wgrad_kernel<MT, false>), grid, dim3(256), lds, s, *d);
+}
+
 extern "C" int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream) {
     if (!desc || !desc->dz || !desc->x || !desc->slab) return HMVAE_ERR_ARG;
     if (desc->bp <= 0 || (desc->bp & 63) || desc->n_tiles <= 0 || desc->n_split <= 0 || desc->kt <= 0) return HMVAE_ERR_ARG;
     if (desc->pad_mode == HMVAE_PAD_REFLECT && desc->pad >= desc->t_src && desc->pad > 0) return HMVAE_ERR_ARG;
     const long long nblk = (long long)desc->n_tiles * desc->n_split;
     if (nblk > 0x7fffffffLL) return HMVAE_ERR_ARG;
-    dim3 grid((unsigned)nblk), block(256);
+    if ((size_t)desc->t_dst * 64 * sizeof(unsigned) > 64 * 1024) return HMVAE_ERR_UNSUPPORTED;   // position table in LDS
+    dim3 grid((unsigned)nblk);
     hipStream_t s = (hipStream_t)stream;
     switch (desc->mt) {
-        case 1: hipLaunchKernelGGL(wgrad_kernel<1>, grid, block, 0, s, *desc); break;
-        case 2: hipLaunchKernelGGL(wgrad_kernel<2>, grid, block, 0, s, *desc); break;
-        case 3: hipLaunchKernelGGL(wgrad_kernel<3>, grid, block, 0, s, *desc); break;
-        case 4: hipLaunchKernelGGL(wgrad_kernel<4>, grid, block, 0, s, *desc); break;
+        case 1: launch_wgrad<1>(desc, grid, s); break;
+        case 2: launch_wgrad<2>(desc, grid, s); break;
+        case 3: launch_wgrad<3>(desc, grid, s); break;
+        case 4: launch_wgrad<4>(desc, grid, s); break;
         default: return HMVAE_ERR_UNSUPPORTED;
     }
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;

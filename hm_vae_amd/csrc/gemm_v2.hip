@@ -1,16 +1,19 @@
-// gemm_v2.hip — gather-GEMM, second generation: register blocking over output positions.
+// gemm_v2.hip — gather-GEMM, second generation (the one the engine launches).
 //
 // Same contract as hmvae_gather_gemm (SkeletonConv forward / backward-data, per-edge Linear; reference
-// skeleton.py:95-105, seq_two_hier_sa_vae.py:162,267) with three changes that the first rocprof pass asked for:
-//   * a wave owns NP consecutive output positions of one (row group, 64-column batch tile).  One 16-byte
-//     activation load (source position q) now feeds the MFMAs of every position whose window contains q, each
-//     with its own tap's weights: activation traffic per MFMA drops ~NP x (the v1 kernel was L1-bound).
-//   * loads run two "items" ahead of the MFMAs (explicit register ring), so a single wave per SIMD keeps the
-//     matrix pipe fed without relying on occupancy.
+// skeleton.py:95-105, seq_two_hier_sa_vae.py:162,267).  What the rocprof/PMC passes on MI355X taught (profiles/):
+//   * v_mfma_f32_16x16x4_f32 runs on the SIMD's fp32 datapath: every other vector instruction a wave issues is
+//     time taken from the matrix pipe (an ablation without MFMAs ran in ~half the time, the two halves add up).
+//     So the loop is on an instruction diet: all table lookups come from LDS copies holding precomputed BYTE
+//     offsets, operand addresses are one 32-bit add on top of a uniform base (saddr loads), the iterator is scalar.
+//   * a wave owns MT*16 rows x CW*64 batch columns of one output position: one weight fragment feeds CW*4 MFMAs and
+//     one 16-byte activation load per 64 columns feeds MT*4 of them.
+//   * loads run DEPTH items ahead of the MFMAs in a ring of statically named register sets (a register that is the
+//     destination of an in-flight load must never be copied; a branch in the steady-state loop makes the compiler
+//     fall back to vmcnt(0)); accumulators are folded into a second level every 96 items, outside the hot loop.
 //   * work units are dealt to the 8 XCDs in group-major contiguous ranges (blockIdx % 8 picks the range), so one
-//     XCD's L2 only ever sees the packed weights of its own few row groups.
-// K can still be split over the 4 waves of a workgroup (ksplit = 4, summed through LDS) for the layers whose
-// grids would otherwise not fill 256 CUs; with ksplit = 1 a workgroup is a single wave and uses no LDS at all.
+//     XCD's L2 only sees the packed weights of its own few row groups.
+// K is split over the 4 waves of a workgroup (summed through LDS) unless a group is too short for that.
 #include <hip/hip_runtime.h>
 #include "hmvae.h"
 
@@ -20,10 +23,10 @@ constexpr int MAX_C4 = 512;         // 4-channel steps per group (host checks)
 constexpr int TABLE_INTS = 2 * MAX_ITEMS + 4 * MAX_C4;
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-template <int MT, int NP>
+template <int MT, int CW>
 struct VStage {          // operands of one item, in flight between its loads and its MFMAs
-    f32x4 b;
-    float a[NP][MT];
+    f32x4 b[CW];         // CW units of 64 batch columns
+    float a[MT];
 };
 struct SStage {          // the item's table entries, read from the LDS copies of the tables (byte offsets)
     unsigned boff;       // activation: (row base of this lane's channel + q*src_ts) * bp * 4
@@ -31,7 +34,7 @@ struct SStage {          // the item's table entries, read from the LDS copies o
     int taps;
 };
 
-template <int MT, int NP, int DEPTH>
+template <int MT, int CW, int DEPTH>
 __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int nwaves = blockDim.x >> 6;
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
     const int per = (d.n_units + 7) >> 3;
     const int u = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per || u >= d.n_units) return;
-    const int n_ct = d.bp >> 6;
+    const int n_ct = d.bp / (64 * CW);
     const int ct = u % n_ct;
     const int r0 = u / n_ct;
     const int n_pq = (d.n_pblk + wpos - 1) / wpos;
@@ -79,13 +82,13 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
     const char* __restrict__ wbase = (const char*)(d.wp + d.g_woff[g]);        // uniform
     const char* __restrict__ sbase = (const char*)d.src;                          // uniform
     const unsigned lane_a = (unsigned)lane * 4u;                                  // this lane's byte offset in an A fragment
-    const unsigned lane_b = (unsigned)((ct << 6) + (n << 2)) * 4u;                // ... in a 64-column batch tile
+    const unsigned lane_b = (unsigned)(ct * (64 * CW) + (n << 2)) * 4u;           // ... in the wave's batch tile
     const int bp = d.bp;
     const int kt = d.kt;
 
-    f32x4 acc[NP][MT][4], tot[NP][MT][4];
+    f32x4 acc[CW][MT][4], tot[CW][MT][4];
 #pragma unroll
-    for (int pl = 0; pl < NP; ++pl)
+    for (int pl = 0; pl < CW; ++pl)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -116,26 +119,23 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
             lit = ok ? (wrap ? 0 : nl) : lit;
             lc4 = ok ? nc : lc4;
         };
-        auto v_issue = [&](const SStage& s, VStage<MT, NP>& v) {
-            static_assert(NP == 1, "one output position per wave (register blocking over positions did not pay)");
-            v.b = *(const f32x4*)(sbase + s.boff);
+        auto v_issue = [&](const SStage& s, VStage<MT, CW>& v) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) v.a[0][mt] = *(const float*)(wbase + s.aoff + mt * 256);
+            for (int cu = 0; cu < CW; ++cu) v.b[cu] = *(const f32x4*)(sbase + s.boff + cu * 256);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) v.a[mt] = *(const float*)(wbase + s.aoff + mt * 256);
         };
-        auto mfma = [&](const VStage<MT, NP>& v, int taps) {
+        auto mfma = [&](const VStage<MT, CW>& v, int) {
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
-                if (NP == 1 || ((__builtin_amdgcn_readfirstlane(taps) >> (8 * pl)) & 0xff) != 0xff) {
+            for (int cu = 0; cu < CW; ++cu)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[pl][mt][j] = MFMA16(v.a[pl][mt], v.b[j], acc[pl][mt][j]);
-                }
-            }
+                    for (int j = 0; j < 4; ++j) acc[cu][mt][j] = MFMA16(v.a[mt], v.b[cu][j], acc[cu][mt][j]);
         };
         auto flush = [&]() {     // fold the short fp32 chain into the running total (two-level accumulation)
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
+            for (int pl = 0; pl < CW; ++pl)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
         // MFMAs of sub-step u while set (u+DEPTH)%(DEPTH+1) is being filled for the item DEPTH ahead.  The table
         // entries of a whole trip are read from LDS one trip ahead into their own registers.
         constexpr int R = DEPTH + 1;
-        VStage<MT, NP> v[R];
+        VStage<MT, CW> v[R];
         SStage c[R], nx[R];
         int tp[R];
 #pragma unroll
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
 #pragma unroll
         for (int u = 0; u < R; ++u) s_fetch(nx[u]);
         const int trips = total / R;
-        constexpr int FLUSH_ITEMS = 48;          // a chain of <= 192 fp32 fmas per accumulator between folds
+        constexpr int FLUSH_ITEMS = 96;          // a chain of <= 384 fp32 fmas per accumulator between folds
         constexpr int FLUSH_TRIPS = (FLUSH_ITEMS + R - 1) / R;
         for (int tb = 0; tb < trips; tb += FLUSH_TRIPS) {
             const int te = tb + FLUSH_TRIPS < trips ? tb + FLUSH_TRIPS : trips;
@@ -186,13 +186,18 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
         flush();
     }
 
-    const int p0 = pb * NP;
+    const int p = pb;
+    if (!live) {
+        if (nw > 1) {          // keep the barriers of the K-split epilogue matched
+            for (int cu = 0; cu < CW; ++cu) { if (cu > 0) __syncthreads(); __syncthreads(); }
+        }
+        return;
+    }
+    const int col0 = ct * (64 * CW);
     if (nw == 1) {
-        // single-wave workgroup: straight from registers, 16 bytes per lane
+        // no K split: straight from registers, 16 bytes per lane
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-            const int p = p0 + pl;
-            if (p >= d.n_pos) break;
+        for (int cu = 0; cu < CW; ++cu)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
                     const int row = mt * 16 + kk * 4 + r;
                     const int drow = d.dst_rows[g * (MT * 16) + row];
                     if (drow < 0) continue;
-                    f32x4 s = {tot[pl][mt][0][r], tot[pl][mt][1][r], tot[pl][mt][2][r], tot[pl][mt][3][r]};
+                    f32x4 s = {tot[cu][mt][0][r], tot[cu][mt][1][r], tot[cu][mt][2][r], tot[cu][mt][3][r]};
                     if (d.bias) {
                         const int bi = d.bias_idx[g * (MT * 16) + row];
                         const float bv = bi >= 0 ? d.bias[bi] : 0.f;
@@ -210,28 +215,25 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) s[e] = s[e] > 0.f ? s[e] : s[e] * d.slope;
                     }
-                    float* dp = d.dst + (size_t)(drow + p * d.dst_ts) * bp + (ct << 6) + (n << 2);
+                    float* dp = d.dst + (size_t)(drow + p * d.dst_ts) * bp + col0 + cu * 64 + (n << 2);
                     if (d.flags & HMVAE_FLAG_ACCUM) s += *(const f32x4*)dp;
                     *(f32x4*)dp = s;
                 }
-        }
         return;
     }
-    // K split over the waves: sum through LDS, one position at a time
+    // K split over the waves: sum through LDS, one 64-column unit at a time
     float* redf = red + TABLE_INTS + 3 * 2 * MAX_ITEMS;
     float* mine = redf + wave * (MT * 16 * 64);
     const int rl = threadIdx.x >> 4;
     const int cq = threadIdx.x & 15;
 #pragma unroll
-    for (int pl = 0; pl < NP; ++pl) {
-        const int p = p0 + pl;
-        if (p >= d.n_pos) break;               // uniform over the workgroup
-        if (pl > 0) __syncthreads();
+    for (int cu = 0; cu < CW; ++cu) {
+        if (cu > 0) __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                f32x4 v = {tot[pl][mt][0][r], tot[pl][mt][1][r], tot[pl][mt][2][r], tot[pl][mt][3][r]};
+                f32x4 v = {tot[cu][mt][0][r], tot[cu][mt][1][r], tot[cu][mt][2][r], tot[cu][mt][3][r]};
                 *(f32x4*)(mine + (mt * 16 + kk * 4 + r) * 64 + (n << 2)) = v;
             }
         __syncthreads();
@@ -249,22 +251,22 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s[e] = s[e] > 0.f ? s[e] : s[e] * d.slope;
             }
-            float* dp = d.dst + (size_t)(drow + p * d.dst_ts) * bp + (ct << 6) + (cq << 2);
+            float* dp = d.dst + (size_t)(drow + p * d.dst_ts) * bp + col0 + cu * 64 + (cq << 2);
             if (d.flags & HMVAE_FLAG_ACCUM) s += *(const f32x4*)dp;
             *(f32x4*)dp = s;
         }
     }
 }
 
-template <int MT, int NP>
+template <int MT, int CW>
 static int launch2(const hmvae_gemm2_desc* d, hipStream_t s) {
     const int per = (d->n_units + 7) / 8;
     dim3 grid((unsigned)(per * 8)), block(64 * (d->wpos > 1 ? d->wpos : d->ksplit));
     const size_t lds = (TABLE_INTS + 3 * 2 * MAX_ITEMS) * sizeof(int) +
                        (d->ksplit > 1 ? (size_t)d->ksplit * MT * 16 * 64 * sizeof(float) : 0);
-    // prefetch distance in items: short MFMA groups (one 16-row tile) need more loads in flight per wave
-    constexpr int DEPTH = (MT * NP == 1) ? 5 : (MT * NP == 2 ? 3 : 2);
-    hipLaunchKernelGGL((gather_gemm2_kernel<MT, NP, DEPTH>), grid, block, lds, s, *d);
+    // prefetch distance in items: short MFMA groups need more loads in flight per wave
+    constexpr int DEPTH = (MT * CW == 1) ? 4 : (MT * CW == 2 ? 3 : 2);
+    hipLaunchKernelGGL((gather_gemm2_kernel<MT, CW, DEPTH>), grid, block, lds, s, *d);
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }
 
@@ -274,16 +276,23 @@ extern "C" int hmvae_gather_gemm_v2(const hmvae_gemm2_desc* desc, hmvae_stream_t
         return HMVAE_ERR_ARG;
     if (desc->ksplit != 1 && desc->ksplit != 2 && desc->ksplit != 4) return HMVAE_ERR_ARG;
     if (desc->max_items <= 0 || desc->max_items > MAX_ITEMS || desc->max_nc4 <= 0 || desc->max_nc4 > MAX_C4) return HMVAE_ERR_UNSUPPORTED;
-    if (desc->n_pblk != (desc->n_pos + desc->np - 1) / desc->np) return HMVAE_ERR_ARG;
+    const int cw = desc->np;            // 64-column units per wave (1, 2 or 4)
+    if (cw != 1 && cw != 2 && cw != 4) return HMVAE_ERR_ARG;
+    if (desc->bp % (64 * cw)) return HMVAE_ERR_ARG;
+    if (desc->n_pblk != desc->n_pos) return HMVAE_ERR_ARG;
     if (desc->wpos != 1 && desc->wpos != 4) return HMVAE_ERR_ARG;
     if (desc->wpos > 1 && desc->ksplit != 1) return HMVAE_ERR_ARG;
-    if ((long long)desc->n_groups * ((desc->n_pblk + desc->wpos - 1) / desc->wpos) * (desc->bp >> 6) != desc->n_units)
+    if ((long long)desc->n_groups * ((desc->n_pblk + desc->wpos - 1) / desc->wpos) * (desc->bp / (64 * cw)) != desc->n_units)
         return HMVAE_ERR_ARG;
+    // 32-bit byte offsets inside the kernel
     hipStream_t s = (hipStream_t)stream;
-    const int key = desc->mt * 10 + desc->np;
+    const int key = desc->mt * 10 + cw;
     switch (key) {
         case 11: return launch2<1, 1>(desc, s);
+        case 12: return launch2<1, 2>(desc, s);
+        case 14: return launch2<1, 4>(desc, s);
         case 21: return launch2<2, 1>(desc, s);
+        case 22: return launch2<2, 2>(desc, s);
         case 31: return launch2<3, 1>(desc, s);
         case 41: return launch2<4, 1>(desc, s);
         default: return HMVAE_ERR_UNSUPPORTED;

@@ -94,10 +94,13 @@ class _Side:
         lib = _lib.load()
         g = self.g
         ch = self.choose(bp)
-        np_, ks = ch[0], ch[1]
+        cw, ks = ch[0], ch[1]
         wpos = ch[2] if len(ch) > 2 else 1
-        pb_off, pb_len, items, n_pblk, max_items = self.items_for(np_)
-        n_units = g.n_groups * (-(-n_pblk // wpos)) * (int(bp) // 64)
+        while int(bp) % (64 * cw):
+            cw //= 2
+        np_ = cw
+        pb_off, pb_len, items, n_pblk, max_items = self.items_for(1)
+        n_units = g.n_groups * (-(-n_pblk // wpos)) * (int(bp) // (64 * cw))
         d = _lib.Gemm2Desc(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(self.wp), _lib.ptr(bias), _lib.ptr(self.bias_idx),
                            _lib.ptr(self.g_nc4), _lib.ptr(self.g_woff), _lib.ptr(self.g_choff), _lib.ptr(self.chan_rows),
                            _lib.ptr(self.dst_rows), _lib.ptr(pb_off), _lib.ptr(pb_len), _lib.ptr(items), g.n_groups, g.mt,

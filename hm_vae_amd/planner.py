@@ -247,17 +247,14 @@ def build_items(pairs, np_):
 
 
 def pick_np_ksplit(mt, n_groups, n_pos, n_col_tiles, avg_nc4, target_waves=2048):
-    """Positions per wave and K split over the waves of a workgroup.
+    """(64-column units per wave, K split over the waves of a workgroup) for the gather-GEMM.
 
-    Measured on MI355X (tools/sweep_gemm.py, B=256): one position per wave with the reduction split over 4 waves wins
-    on every layer of the len64 model — the kernel is bound by L2->L1 operand bandwidth per CU, and more resident
-    waves (not more registers per wave) is what keeps loads in flight.  K is only left unsplit when a group has too
-    few 4-channel steps to give every wave a pipelined loop.
+    Measured on MI355X (tools/sweep_gemm.py, B=256).  fp32 MFMA shares the SIMD's fp32 datapath with ordinary vector
+    instructions, so the more MFMAs a wave issues per item (mt*cw*4) the smaller the share lost to addressing; but
+    the grid must still put a couple of waves on each of the 1024 SIMDs.
     """
-    if avg_nc4 >= 8:
-        ks = 4
-    elif avg_nc4 >= 4:
-        ks = 2
-    else:
-        ks = 1
-    return 1, ks
+    ks = 4 if avg_nc4 >= 8 else (2 if avg_nc4 >= 4 else 1)
+    cw = 1
+    if mt == 1 and n_col_tiles % 2 == 0 and n_groups * n_pos * (n_col_tiles // 2) * ks >= 5000:
+        cw = 2
+    return cw, ks

@@ -70,10 +70,10 @@ typedef struct {
 
 int hmvae_gather_gemm(const hmvae_gemm_desc* desc, hmvae_stream_t stream);
 
-/* Second-generation gather-GEMM: a wave owns `np` consecutive output positions and walks a per-position-block
- * list of "items" (source position q + one tap per owned position, 0xff = this position does not read q), so one
- * activation load feeds up to np MFMA groups.  Same maths and weight layout as hmvae_gather_gemm.
- * Work unit = (group, position block, 64-column tile); units are dealt to XCDs in contiguous group-major ranges. */
+/* Second-generation gather-GEMM (the one the engine uses): same maths and weight layout as hmvae_gather_gemm; a
+ * wave owns mt*16 rows x np*64 batch columns of ONE output position and walks that position's list of "items"
+ * (source position q, tap) with its operand loads software-pipelined.  Work unit = (group, position, np*64-column
+ * tile); units are dealt to XCDs in contiguous group-major ranges.  `np` = 64-column units per wave (1, 2 or 4). */
 typedef struct {
     const float* src;
     float* dst;

@@ -35,7 +35,6 @@ for name, op in zip(names, convs):
         mt = side.g.mt
         res = []
         for np_ in {1: (1, 2, 4), 2: (1, 2), 3: (1,), 4: (1,)}[mt]:
-            if np_ > side.n_pos: continue
             for ks in (1, 2, 4):
                 side.tune = (np_, ks)
                 out.zero_()
@@ -43,19 +42,12 @@ for name, op in zip(names, convs):
                 err = float((out - ref).abs().max() / ref.abs().max())
                 t = timeit(lambda: side.run_v2(src, out, bp))
                 res.append((t, np_, ks, err))
-        for wp in (4,):
-            side.tune = (1, 1, wp)
-            out.zero_()
-            side.run_v2(src, out, bp)
-            err = float((out - ref).abs().max() / ref.abs().max())
-            t = timeit(lambda: side.run_v2(src, out, bp))
-            res.append((t, 1, 10 + wp, err))
         side.tune = None
         auto = side.choose(bp)
         res.sort()
         best_total += res[0][0]
         t_auto = [r[0] for r in res if (r[1], r[2]) == tuple(auto)][0]
-        print("%s %s mt%d groups %3d pos %2d | v1 %7.1f us | best v2 %7.1f us (np%d ks%d) %5.1f TF eff | auto (np%d ks%d) %7.1f us | maxerr %.1e | all: %s" % (
+        print("%s %s mt%d groups %3d pos %2d | v1 %7.1f us | best v2 %7.1f us (cw%d ks%d) %5.1f TF eff | auto (cw%d ks%d) %7.1f us | maxerr %.1e | all: %s" % (
             name, dirn, mt, side.g.n_groups, side.n_pos, t1, res[0][0], res[0][1], res[0][2], useful / res[0][0] / 1e6, auto[0], auto[1], t_auto,
-            max(r[3] for r in res), " ".join("np%dks%d:%.0f" % (r[1], r[2], r[0]) for r in res)))
+            max(r[3] for r in res), " ".join("cw%dks%d:%.0f" % (r[1], r[2], r[0]) for r in res)))
 print("sum v1 %.0f us, sum best v2 %.0f us" % (v1_total, best_total))
