@@ -40,7 +40,7 @@ class WgradDesc(C.Structure):
     _fields_ = [("dz", _ptr), ("x", _ptr), ("slab", _ptr), ("tile_g", _ptr), ("tile_col0", _ptr), ("g_ncols", _ptr),
                 ("g_choff", _ptr), ("chan_rows", _ptr), ("dz_rows", _ptr), ("n_tiles", _i32), ("n_groups", _i32),
                 ("mt", _i32), ("kt", _i32), ("n_split", _i32), ("t_dst", _i32), ("t_src", _i32), ("stride", _i32),
-                ("pad", _i32), ("pad_mode", _i32), ("bp", _i32), ("dz_ts", _i32), ("x_ts", _i32)]
+                ("pad", _i32), ("pad_mode", _i32), ("bp", _i32), ("dz_ts", _i32), ("x_ts", _i32), ("transposed", _i32)]
 
 
 class WreduceDesc(C.Structure):
@@ -65,7 +65,7 @@ _SIGS = {
     "hmvae_gather_gemm_v2": ([C.POINTER(Gemm2Desc), _ptr], _i32),
     "hmvae_wgrad_gemm": ([C.POINTER(WgradDesc), _ptr], _i32),
     "hmvae_wgrad_reduce": ([C.POINTER(WreduceDesc), _ptr], _i32),
-    "hmvae_pack_weights": ([_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
+    "hmvae_pack_weights": ([_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_pool_leaky_fwd": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),
     "hmvae_pool_leaky_bwd": ([_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),
     "hmvae_upsample_unpool_fwd": ([_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
@@ -81,6 +81,7 @@ _SIGS = {
     "hmvae_decode_tail_loss": ([_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _f32, _f32, _f32, _ptr, _ptr,
                                 C.POINTER(_i32), _ptr], _i32),
     "hmvae_decode_tail_fwd": ([_ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr, _ptr, _ptr], _i32),
+    "hmvae_vae_loss_finalize": ([_ptr, _i32, _ptr, _i32, _ptr, _i32] + [_f32] * 10 + [_ptr, _ptr], _i32),
     "hmvae_finalize_sums": ([_ptr, _i32, _i32, _i32, _f32, _ptr, _ptr], _i32),
     "hmvae_adam_step": ([_ptr, _i32, _i64, _ptr, _ptr, _f32, _f32, _f32, _f32, _ptr], _i32),
 }

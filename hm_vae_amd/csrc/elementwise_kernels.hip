@@ -390,6 +390,49 @@ extern "C" int hmvae_finalize_sums(const float* partial, int32_t n_partial, int3
     return LAUNCH_OK();
 }
 
+__global__ __launch_bounds__(256) void vae_loss_finalize_kernel(const float* __restrict__ mse, int n_mse,
+                                                                 const float* __restrict__ kl0, int n_kl0,
+                                                                 const float* __restrict__ kld, int n_kld, float inv_n6,
+                                                                 float inv_nR, float inv_nP, float inv_r0, float inv_rd,
+                                                                 float w6, float wR, float wP, float wkl, float wskl,
+                                                                 float* __restrict__ out) {
+    __shared__ float sh[4];
+    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < n_mse; i += 256) {
+        s[0] += mse[(size_t)i * 3];
+        s[1] += mse[(size_t)i * 3 + 1];
+        s[2] += mse[(size_t)i * 3 + 2];
+    }
+    for (int i = threadIdx.x; i < n_kl0; i += 256) s[3] += kl0[i];
+    for (int i = threadIdx.x; i < n_kld; i += 256) s[4] += kld[i];
+    float r[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) r[k] = block_sum256(s[k], sh);
+    if (threadIdx.x == 0) {
+        const float l6 = r[0] * inv_n6, lR = r[1] * inv_nR, lP = r[2] * inv_nP;
+        const float k0 = r[3] * inv_r0, kd = r[4] * inv_rd;
+        const float lkl = wkl * kd + wskl * k0;
+        out[0] = w6 * l6 + wR * lR + wP * lP + wkl * kd + wskl * k0;
+        out[1] = lkl;
+        out[2] = l6;
+        out[3] = lR;
+        out[4] = lP;
+        out[5] = k0;
+        out[6] = kd;
+        out[7] = 0.f;
+    }
+}
+
+extern "C" int hmvae_vae_loss_finalize(const float* mse_partial, int32_t n_mse, const float* kl0_partial, int32_t n_kl0,
+                                       const float* kld_partial, int32_t n_kld, float inv_n6, float inv_nR, float inv_nP,
+                                       float inv_rows0, float inv_rowsd, float w6, float wR, float wP, float w_kl,
+                                       float w_skl, float* out8, hmvae_stream_t stream) {
+    if (!mse_partial || !kl0_partial || !kld_partial || !out8 || n_mse <= 0 || n_kl0 <= 0 || n_kld <= 0) return HMVAE_ERR_ARG;
+    hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mse_partial, n_mse, kl0_partial,
+                       n_kl0, kld_partial, n_kld, inv_n6, inv_nR, inv_nP, inv_rows0, inv_rowsd, w6, wR, wP, w_kl, w_skl, out8);
+    return LAUNCH_OK();
+}
+
 // ---------------- Adam ----------------
 __global__ __launch_bounds__(256) void adam_kernel(const hmvae_adam_tensor* __restrict__ tab,
                                                     const float* __restrict__ lr_dev, const int* __restrict__ step_dev,

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
     const int bp = d.bp;
     const int ncols = d.g_ncols[g];
     const int choff = d.g_choff[g];
-    const int T = d.t_dst;
+    const bool TR = d.transposed != 0;
+    const int T = TR ? d.t_src + 2 * d.pad : d.t_dst;        // positions the reduction walks over
 
     // table: column c = threadIdx & 63 of this tile, positions t = wave, wave+4, ...   (all address arithmetic that
     // depends on (t, tap) happens here, once; the loop only adds a scalar base — fp32 MFMA shares the SIMD's fp32
@@ -220,7 +221,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
         for (int t = threadIdx.x >> 6; t < T; t += 4) {
             int u = t * d.stride + tp - d.pad;
             unsigned v;
-            if (d.pad_mode == HMVAE_PAD_REFLECT) {
+            if (TR) {
+                // column = (output channel, tap) of dz: padded input position t feeds output position t - tap
+                const int td = t - tp;
+                v = (td >= 0 && td < d.t_dst) ? (unsigned)(xr + td * d.dz_ts) * (unsigned)bp * 4u : 0xffffffffu;
+            } else if (d.pad_mode == HMVAE_PAD_REFLECT) {
                 if (u < 0) u = -u;
                 if (u >= d.t_src) u = 2 * (d.t_src - 1) - u;
                 v = (unsigned)(xr + u * d.x_ts) * (unsigned)bp * 4u;
@@ -256,9 +261,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
     const long long total = (long long)T * nb32;
     const int lo = (int)(total * sp / d.n_split);
     const int hi = (int)(total * (sp + 1) / d.n_split);
-    const char* __restrict__ dzb = (const char*)d.dz;
-    const char* __restrict__ xb = (const char*)d.x;
-    const unsigned dz_tstep = (unsigned)d.dz_ts * (unsigned)bp * 4u;
+    const char* __restrict__ dzb = (const char*)(TR ? d.x : d.dz);       // row operand
+    const char* __restrict__ xb = (const char*)(TR ? d.dz : d.x);        // column operand
+    const unsigned dz_tstep = (unsigned)(TR ? d.x_ts : d.dz_ts) * (unsigned)bp * 4u;
+    const int pad = d.pad, tsrc = d.t_src;
     struct Ops {
         f32x4 a[MT][2];
         f32x4 b[4][2];
@@ -266,7 +272,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
     auto load = [&](Ops& o, int chunk) {
         const int bb = chunk / T;            // scalar
         const int t = chunk - bb * T;
-        const char* dzs = dzb + (size_t)t * dz_tstep + (size_t)(bb << 7);      // uniform base for this chunk
+        int tr = t;
+        if (TR) {                            // row operand sits at the reflected source position of padded position t
+            tr = t - pad;
+            tr = tr < 0 ? -tr : tr;
+            tr = tr >= tsrc ? 2 * (tsrc - 1) - tr : tr;
+        }
+        const char* dzs = dzb + (size_t)tr * dz_tstep + (size_t)(bb << 7);     // uniform base for this chunk
         const char* xs = xb + (size_t)(bb << 7);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -361,7 +373,10 @@ static void launch_wgrad(const hmvae_wgrad_desc* d, dim3 grid, hipStream_t s) {
     size_t lds = (size_t)4 * MT * 16 * 64 * sizeof(float);
     const size_t tab = (size_t)d->t_dst * 64 * sizeof(unsigned);
     if (tab > lds) lds = tab;
-    if (d->pad_mode == HMVAE_PAD_ZEROS) hipLaunchKernelGGL((wgrad_kernel<MT, true>), grid, dim3(256), lds, s, *d);
+    const int npos = d->transposed ? d->t_src + 2 * d->pad : d->t_dst;
+    const size_t tab2 = (size_t)npos * 64 * sizeof(unsigned);
+    if (tab2 > lds) lds = tab2;
+    if (d->pad_mode == HMVAE_PAD_ZEROS || d->transposed) hipLaunchKernelGGL((wgrad_kernel<MT, true>), grid, dim3(256), lds, s, *d);
     else hipLaunchKernelGGL((wgrad_kernel<MT, false>), grid, dim3(256), lds, s, *d);
 }
 
@@ -371,7 +386,11 @@ extern "C" int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t str
     if (desc->pad_mode == HMVAE_PAD_REFLECT && desc->pad >= desc->t_src && desc->pad > 0) return HMVAE_ERR_ARG;
     const long long nblk = (long long)desc->n_tiles * desc->n_split;
     if (nblk > 0x7fffffffLL) return HMVAE_ERR_ARG;
-    if ((size_t)desc->t_dst * 64 * sizeof(unsigned) > 64 * 1024) return HMVAE_ERR_UNSUPPORTED;   // position table in LDS
+    if (desc->transposed && (desc->stride != 1 || desc->pad_mode != HMVAE_PAD_REFLECT)) return HMVAE_ERR_UNSUPPORTED;
+    {
+        const int npos = desc->transposed ? desc->t_src + 2 * desc->pad : desc->t_dst;
+        if ((size_t)npos * 64 * sizeof(unsigned) > 64 * 1024) return HMVAE_ERR_UNSUPPORTED;       // position table in LDS
+    }
     dim3 grid((unsigned)nblk);
     hipStream_t s = (hipStream_t)stream;
     switch (desc->mt) {
@@ -419,6 +438,9 @@ extern "C" int hmvae_wgrad_reduce(const hmvae_wreduce_desc* desc, hmvae_stream_t
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }
 
+// One workgroup per (group, 4-channel step): the 64 (kk, m) lanes each own one (row, channel) pair and walk its taps,
+// so the ids / mask are looked up once per lane and the kt taps of a pair (contiguous in the dense tensor in the
+// forward layout) are read by one lane back to back.  Writes are whole 256-byte MFMA fragments.
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ dense, float* __restrict__ packed,
                                                    const int* __restrict__ g_nc4, const int* __restrict__ g_woff,
                                                    const int* __restrict__ g_choff, const int* __restrict__ chan_id,
@@ -426,34 +448,33 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ den
                                                    const unsigned char* __restrict__ pair_ok, int mt, int kt, int row_stride,
                                                    int chan_stride, int tap_stride, int tap_flip) {
     const int g = blockIdx.y;
-    const int per_c4 = kt * mt * 64;
-    const int total = g_nc4[g] * per_c4;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
-        const int c4 = idx / per_c4;
-        int rem = idx - c4 * per_c4;
-        const int tap = rem / (mt * 64);
-        rem -= tap * (mt * 64);
-        const int m_t = rem >> 6;
-        const int l = rem & 63;
-        const int kk = l >> 4, m = l & 15;
+    const int c4 = blockIdx.x;
+    const int nc4 = g_nc4[g];
+    if (c4 >= nc4) return;
+    const int l = threadIdx.x & 63;
+    const int sub = threadIdx.x >> 6;
+    const int kk = l >> 4, m = l & 15;
+    const int cid = chan_id[g_choff[g] + c4 * 4 + kk];
+    float* out = packed + g_woff[g] + (size_t)c4 * kt * mt * 64 + l;
+    for (int m_t = 0; m_t < mt; ++m_t) {
         const int rid = row_id[g * (mt * 16) + m_t * 16 + m];
-        const int cid = chan_id[g_choff[g] + c4 * 4 + kk];
-        float v = 0.f;
-        if (rid >= 0 && cid >= 0 && pair_ok[g_okoff[g] + (m_t * 16 + m) * (g_nc4[g] * 4) + c4 * 4 + kk]) {
+        const bool ok = rid >= 0 && cid >= 0 && pair_ok[g_okoff[g] + (m_t * 16 + m) * (nc4 * 4) + c4 * 4 + kk];
+        const float* src = dense + (ok ? (size_t)rid * row_stride + (size_t)cid * chan_stride : 0);
+        for (int tap = sub; tap < kt; tap += 4) {
             const int td = tap_flip ? (kt - 1 - tap) : tap;
-            v = dense[(size_t)rid * row_stride + (size_t)cid * chan_stride + (size_t)td * tap_stride];
+            out[(size_t)(tap * mt + m_t) * 64] = ok ? src[(size_t)td * tap_stride] : 0.f;
         }
-        packed[g_woff[g] + idx] = v;
     }
 }
 
 extern "C" int hmvae_pack_weights(const float* dense, float* packed, const int32_t* g_nc4, const int32_t* g_woff,
                                   const int32_t* g_choff, const int32_t* chan_id, const int32_t* row_id,
-                                  const int32_t* g_okoff, const uint8_t* pair_ok, int32_t n_groups, int32_t mt,
-                                  int32_t kt, int32_t row_stride, int32_t chan_stride, int32_t tap_stride,
+                                  const int32_t* g_okoff, const uint8_t* pair_ok, int32_t n_groups, int32_t max_nc4,
+                                  int32_t mt, int32_t kt, int32_t row_stride, int32_t chan_stride, int32_t tap_stride,
                                   int32_t tap_flip, hmvae_stream_t stream) {
-    if (!dense || !packed || !g_okoff || !pair_ok || n_groups <= 0 || mt < 1 || mt > 4 || kt <= 0) return HMVAE_ERR_ARG;
-    dim3 grid(64, (unsigned)n_groups), block(256);
+    if (!dense || !packed || !g_okoff || !pair_ok || n_groups <= 0 || max_nc4 <= 0 || mt < 1 || mt > 4 || kt <= 0)
+        return HMVAE_ERR_ARG;
+    dim3 grid((unsigned)max_nc4, (unsigned)n_groups), block(256);
     hipLaunchKernelGGL(pack_kernel, grid, block, 0, (hipStream_t)stream, dense, packed, g_nc4, g_woff, g_choff, chan_id,
                        row_id, g_okoff, pair_ok, mt, kt, row_stride, chan_stride, tap_stride, tap_flip);
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;

@@ -315,16 +315,9 @@ class VaeEngine:
         ops.decode_tail_loss(w["D%d" % (L - 1)], w["X0"], w["GR"], w["GP"], self.offsets, T, B, bp,
                              hp["rec_6d_w"] / n6, hp["rec_rot_w"] / nR, hp["rec_pose_w"] / nP, w["dD%d" % (L - 1)], w["MSEP"])
         ls = w["losses"]
-        nblk = w["MSEP"].shape[0]
-        ops.finalize_sum(w["MSEP"], nblk, 3, 0, 1.0 / n6, ls[2:3])
-        ops.finalize_sum(w["MSEP"], nblk, 3, 1, 1.0 / nR, ls[3:4])
-        ops.finalize_sum(w["MSEP"], nblk, 3, 2, 1.0 / nP, ls[4:5])
-        ops.finalize_sum(w["KLP0"], w["KLP0"].numel(), 1, 0, 1.0 / (B * p.edge_num[1]), ls[5:6])
-        ops.finalize_sum(w["KLP%d" % (L - 1)], w["KLP%d" % (L - 1)].numel(), 1, 0, 1.0 / (B * p.edge_num[L]), ls[6:7])
-        # l_kl and l_total (:408-411)
-        torch.add(ls[6] * hp["kl_w"], ls[5], alpha=hp["shallow_kl_w"], out=ls[1])
-        tot = ls[2] * hp["rec_6d_w"] + ls[3] * hp["rec_rot_w"] + ls[4] * hp["rec_pose_w"] + ls[1]
-        ls[0].copy_(tot)
+        ops.vae_loss_finalize(w["MSEP"], w["KLP0"], w["KLP%d" % (L - 1)], 1.0 / n6, 1.0 / nR, 1.0 / nP,
+                              1.0 / (B * p.edge_num[1]), 1.0 / (B * p.edge_num[L]), hp["rec_6d_w"], hp["rec_rot_w"],
+                              hp["rec_pose_w"], hp["kl_w"], hp["shallow_kl_w"], ls)
         if backward:
             self._backward(w, phase2, eps, B, bp)
             self.assign_grads(phase2)

@@ -69,8 +69,8 @@ class _Side:
         rs, cs, ts = self.strides
         _lib.check(lib.hmvae_pack_weights(_lib.ptr(dense), _lib.ptr(self.wp), _lib.ptr(self.g_nc4), _lib.ptr(self.g_woff),
                                           _lib.ptr(self.g_choff), _lib.ptr(self.chan_id), _lib.ptr(self.row_id),
-                                          _lib.ptr(self.g_okoff), _lib.ptr(self.pair_ok), g.n_groups, g.mt, g.kt, rs, cs,
-                                          ts, 0, _lib.stream()), "pack_weights")
+                                          _lib.ptr(self.g_okoff), _lib.ptr(self.pair_ok), g.n_groups, int(g.g_nc4.max()),
+                                          g.mt, g.kt, rs, cs, ts, 0, _lib.stream()), "pack_weights")
 
     def items_for(self, np_):
         if np_ not in self._items:
@@ -144,17 +144,46 @@ class MaskedGemm:
             gb = P.make_groups(rows_b, chans_b, kt)
             # transposed: "rows" are forward channels, "channels" are forward rows
             self.bwd = _Side(device, gb, pairs_b, y_base, x_base, None, y_ts, x_ts, (kt, n_chan * kt, 1))
-        # weight gradient tiles (forward grouping)
-        tile_g, tile_col0, g_ncols = gf.wgrad_tiles()
+        # weight gradient tiles: forward grouping, or (masked convs) a grouping keyed by input block whose tiles have
+        # several 16-row pieces per activation load and no union waste
+        gw = gf
+        if rows_b is not None and len(rows_b) > 1 and _os.environ.get("HMVAE_WGRAD_G", "1") != "0":
+            cand = P.make_wgrad_groups(rows_b, chans_b, kt)
+            t_f = sum(-(-int(nn) * kt // 64) for nn in gf.g_nch) * gf.mt * (1.0 + 0.35 / gf.mt)
+            t_c = sum(-(-int(nn) * kt // 64) for nn in cand.g_nch) * cand.mt * (1.0 + 0.35 / cand.mt)
+            if t_c < t_f:
+                gw = cand
+        self.wg = gw
+        self.wg_tabs = dict(row_id=_dev(gw.row_id, device), chan_id=_dev(gw.chan_id, device), g_nc4=_dev(gw.g_nc4, device),
+                            g_choff=_dev(gw.g_choff, device), g_okoff=_dev(gw.g_okoff, device),
+                            pair_ok=_dev(gw.pair_ok, device))
+        chw = gw.chan_id
+        self.wg_chan_rows = _dev(np.where(chw >= 0, x_base[np.maximum(chw, 0)], x_base[int(chw[chw >= 0][0])]).astype(np.int32),
+                                 device)
+        tile_g, tile_col0, g_ncols = gw.wgrad_tiles()
         self.n_tiles = len(tile_g)
         self.tile_g, self.tile_col0, self.g_ncols = _dev(tile_g, device), _dev(tile_col0, device), _dev(g_ncols, device)
-        ri = gf.row_id
+        ri = gw.row_id
         self.dz_rows = _dev(np.where(ri >= 0, y_base[np.maximum(ri, 0)], -1).astype(np.int32), device)
         self.x_ts, self.y_ts = int(x_ts), int(y_ts)
         # geometry of the position reduction for the weight gradient
         self.geom = conv_geom or dict(t_dst=len(pairs_f), t_src=len(pairs_f), stride=1, pad=0, pad_mode=_lib.PAD_REFLECT)
         self.useful_macs_per_col = gf.useful() * kt * len(pairs_f)      # MACs per batch column, forward
         self.mfma_macs_per_col = gf.mfma_cost() * kt * len(pairs_f)
+        # weight-gradient orientation: rows = output channels (standard) or rows = input channels walked over the padded
+        # positions (transposed; stride-1 reflect convs only).  Pick the one that issues fewer MFMAs.
+        self.wg_transposed = False
+        ge = self.geom
+        if (self.bwd is not None and ge["stride"] == 1 and ge["pad_mode"] == _lib.PAD_REFLECT and ge["pad"] > 0
+                and _os.environ.get("HMVAE_WGRAD_T", "1") != "0"):
+            gb = self.bwd.g
+            tg_t, tc_t, nc_t = gb.wgrad_tiles()
+            cost_std = self.n_tiles * gw.mt * ge["t_dst"]
+            cost_tr = len(tg_t) * gb.mt * (ge["t_src"] + 2 * ge["pad"])
+            if cost_tr < 0.85 * cost_std:
+                self.wg_transposed = True
+                self.n_tiles_t = len(tg_t)
+                self.tile_g_t, self.tile_col0_t, self.g_ncols_t = _dev(tg_t, device), _dev(tc_t, device), _dev(nc_t, device)
 
     # -- passes --
     def pack(self, weight):
@@ -169,29 +198,60 @@ class MaskedGemm:
         self.bwd.run(dy, dx, bp, None, _lib.FLAG_ACCUM if accumulate else 0)
 
     def n_split(self, bp):
+        if self.wg_transposed:
+            return P.pick_split(self.n_tiles_t, (self.geom["t_src"] + 2 * self.geom["pad"]) * (bp // 32))
         return P.pick_split(self.n_tiles, self.geom["t_dst"] * (bp // 32))
 
     def slab_floats(self, bp):
-        return self.n_split(bp) * self.n_tiles * self.fwd.g.mt * 16 * 64
+        if self.wg_transposed:
+            return self.n_split(bp) * self.n_tiles_t * self.bwd.g.mt * 16 * 64
+        return self.n_split(bp) * self.n_tiles * self.wg.mt * 16 * 64
 
     def backward_weight(self, dy, x, dw, bp, slab, accumulate=False):
+        if self.wg_transposed:
+            return self._backward_weight_t(dy, x, dw, bp, slab, accumulate)
         lib = _lib.load()
-        g = self.fwd.g
+        g = self.wg
+        tb = self.wg_tabs
         ns = self.n_split(bp)
         assert slab.numel() >= ns * self.n_tiles * g.mt * 16 * 64
         ge = self.geom
         d = _lib.WgradDesc(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(slab), _lib.ptr(self.tile_g), _lib.ptr(self.tile_col0),
-                           _lib.ptr(self.g_ncols), _lib.ptr(self.fwd.g_choff), _lib.ptr(self.fwd.chan_rows),
+                           _lib.ptr(self.g_ncols), _lib.ptr(tb["g_choff"]), _lib.ptr(self.wg_chan_rows),
                            _lib.ptr(self.dz_rows), self.n_tiles, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"],
-                           ge["stride"], ge["pad"], ge["pad_mode"], int(bp), self.y_ts, self.x_ts)
+                           ge["stride"], ge["pad"], ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 0)
         _lib.check(lib.hmvae_wgrad_gemm(C.byref(d), _lib.stream()), "wgrad_gemm")
         n_rows, n_chan, kt = self.w_shape
         r = _lib.WreduceDesc(_lib.ptr(slab), _lib.ptr(dw), _lib.ptr(self.tile_g), _lib.ptr(self.tile_col0),
-                             _lib.ptr(self.g_ncols), _lib.ptr(self.fwd.g_choff), _lib.ptr(self.fwd.chan_id),
-                             _lib.ptr(self.fwd.row_id), _lib.ptr(self.fwd.g_nc4), _lib.ptr(self.fwd.g_okoff),
-                             _lib.ptr(self.fwd.pair_ok), self.n_tiles, g.mt, g.kt, ns, n_chan * kt, kt,
+                             _lib.ptr(self.g_ncols), _lib.ptr(tb["g_choff"]), _lib.ptr(tb["chan_id"]),
+                             _lib.ptr(tb["row_id"]), _lib.ptr(tb["g_nc4"]), _lib.ptr(tb["g_okoff"]),
+                             _lib.ptr(tb["pair_ok"]), self.n_tiles, g.mt, g.kt, ns, n_chan * kt, kt,
                              1 if accumulate else 0)
         _lib.check(lib.hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce")
+
+
+def _mg_backward_weight_t(self, dy, x, dw, bp, slab, accumulate=False):
+    """Transposed orientation (see hmvae_wgrad_desc.transposed): tiles come from the backward-data grouping."""
+    lib = _lib.load()
+    b = self.bwd
+    g = b.g
+    ns = self.n_split(bp)
+    assert slab.numel() >= ns * self.n_tiles_t * g.mt * 16 * 64
+    ge = self.geom
+    d = _lib.WgradDesc(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(slab), _lib.ptr(self.tile_g_t), _lib.ptr(self.tile_col0_t),
+                       _lib.ptr(self.g_ncols_t), _lib.ptr(b.g_choff), _lib.ptr(b.chan_rows), _lib.ptr(b.dst_rows),
+                       self.n_tiles_t, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"], ge["stride"], ge["pad"],
+                       ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 1)
+    _lib.check(lib.hmvae_wgrad_gemm(C.byref(d), _lib.stream()), "wgrad_gemm(T)")
+    n_rows, n_chan, kt = self.w_shape
+    r = _lib.WreduceDesc(_lib.ptr(slab), _lib.ptr(dw), _lib.ptr(self.tile_g_t), _lib.ptr(self.tile_col0_t),
+                         _lib.ptr(self.g_ncols_t), _lib.ptr(b.g_choff), _lib.ptr(b.chan_id), _lib.ptr(b.row_id),
+                         _lib.ptr(b.g_nc4), _lib.ptr(b.g_okoff), _lib.ptr(b.pair_ok), self.n_tiles_t, g.mt, g.kt, ns, kt,
+                         n_chan * kt, 1 if accumulate else 0)
+    _lib.check(lib.hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce(T)")
+
+
+MaskedGemm._backward_weight_t = _mg_backward_weight_t
 
 
 def conv_gemm(device, neigh, cin, cout, kt, stride, pad, pad_mode, t_in, need_dx=True, out_chan_map=None):
@@ -363,3 +423,11 @@ def decode_tail_fwd(dec, offsets, T, B, bp, c6, R, pos):
 def finalize_sum(partial, n_partial, stride, k, scale, out):
     _lib.check(_lib.load().hmvae_finalize_sums(_lib.ptr(partial), n_partial, stride, k, float(scale), _lib.ptr(out),
                                                _lib.stream()), "finalize_sums")
+
+
+def vae_loss_finalize(mse_partial, kl0_partial, kld_partial, inv_n6, inv_nR, inv_nP, inv_rows0, inv_rowsd, w6, wR, wP, w_kl,
+                      w_skl, out8):
+    _lib.check(_lib.load().hmvae_vae_loss_finalize(_lib.ptr(mse_partial), mse_partial.shape[0], _lib.ptr(kl0_partial),
+                                                   kl0_partial.numel(), _lib.ptr(kld_partial), kld_partial.numel(),
+                                                   inv_n6, inv_nR, inv_nP, inv_rows0, inv_rowsd, w6, wR, wP, w_kl, w_skl,
+                                                   _lib.ptr(out8), _lib.stream()), "vae_loss_finalize")

@@ -157,6 +157,31 @@ def conv_joint_lists_transposed(neigh, cin, cout):
     return rows, [sorted(c) for c in chans]
 
 
+def make_wgrad_groups(rows_b, chans_b, kt, mt_choices=(4, 3, 2, 1)):
+    """Weight-gradient tiling keyed by INPUT block: columns = the block's channels x taps, rows = every output row
+    that reads the block (all of them read all of its channels, so there is no union waste), cut into 16*mt-row
+    pieces.  rows_b / chans_b are the transposed lists (conv_joint_lists_transposed): rows_b[k] = channels of input
+    block k, chans_b[k] = output rows that read it.  Returns the GroupSet with the fewest MFMA tile-rows."""
+    best = None
+    for mt in mt_choices:
+        cap = 16 * mt
+        groups = []
+        for in_ch, out_rows in zip(rows_b, chans_b):
+            out_rows = list(out_rows)
+            n_chunks = -(-len(out_rows) // cap)
+            # even split keeps the last piece from being nearly empty
+            per = -(-len(out_rows) // n_chunks)
+            per = -(-per // 16) * 16 if per % 16 else per
+            for k in range(0, len(out_rows), per):
+                groups.append((out_rows[k:k + per], list(in_ch)))
+        gs = GroupSet(mt, groups, kt, None)
+        tiles = sum(-(-int(n) * kt // 64) for n in gs.g_nch)
+        cost = tiles * mt * (1.0 + 0.35 / mt)          # fewer, fatter tiles reuse the activation operand more
+        if best is None or cost < best[0]:
+            best = (cost, gs)
+    return best[1]
+
+
 def reflect(u, n):
     if u < 0:
         u = -u

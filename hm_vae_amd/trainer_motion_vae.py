@@ -47,10 +47,11 @@ class Trainer(nn.Module):
         out = model(data, hp, iterations, multigpus=multigpus, validation_flag=validation_flag)
         kl_list = out[9]
         prefix = "loss_val_" if validation_flag else "loss_"
+        # the reference takes torch.mean of each (a no-op unless nn.DataParallel gathered one value per replica)
         for name, val in zip(_LOSS_NAMES, out[:9]):
-            setattr(self, prefix + name, torch.mean(val))
+            setattr(self, prefix + name, val if val.numel() == 1 else torch.mean(val))
         for i, k in enumerate(kl_list):
-            setattr(self, "loss_hier_kl_%d" % (i + 1), torch.mean(k))
+            setattr(self, "loss_hier_kl_%d" % (i + 1), k if k.numel() == 1 else torch.mean(k))
         if not validation_flag:
             eng = model.engine()
             if ddp.is_distributed():
@@ -58,7 +59,11 @@ class Trainer(nn.Module):
             self.gen_opt.step()
             if self.gen_scheduler is not None:
                 self.gen_scheduler.step()
-        # one device->host transfer for the nine scalars the reference fetched with nine .item() calls
+        # one device->host transfer for the scalars the reference fetched with nine .item() calls
+        eng_losses = getattr(model, "last_losses", None)
+        if eng_losses is not None:
+            v = eng_losses.tolist()
+            return (v[0], v[1], v[2], v[3], v[4], 0.0, 0.0, 0.0, 0.0)
         vals = torch.stack([getattr(self, prefix + n).reshape(()) for n in _LOSS_NAMES]).tolist()
         return tuple(vals)
 

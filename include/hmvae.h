@@ -118,6 +118,12 @@ typedef struct {
     int32_t n_tiles, n_groups, mt, kt, n_split;
     int32_t t_dst, t_src, stride, pad, pad_mode, bp;
     int32_t dz_ts, x_ts;
+    int32_t transposed;      /* 0: rows = output channels (dz), columns = (input channel, tap) read from x.
+                                1 (stride 1, reflect only): rows = input channels (x, walked over the PADDED positions),
+                                columns = (output channel, tap) read from dz at t' - tap, zero outside [0, t_dst);
+                                then dz_rows holds x row bases and chan_rows holds dz row bases.  Same FLOPs per useful
+                                weight, but the 16-row MFMA tiles are filled by the many input channels instead of the
+                                few (6..12) output channels of a joint. */
 } hmvae_wgrad_desc;
 
 int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream);
@@ -146,7 +152,7 @@ int hmvae_wgrad_reduce(const hmvae_wreduce_desc* desc, hmvae_stream_t stream);
  * (0 for -1 ids and for (row, channel) pairs outside the mask: this is skeleton.py:96 `weight * mask`) */
 int hmvae_pack_weights(const float* dense, float* packed, const int32_t* g_nc4, const int32_t* g_woff,
                        const int32_t* g_choff, const int32_t* chan_id, const int32_t* row_id,
-                       const int32_t* g_okoff, const uint8_t* pair_ok, int32_t n_groups,
+                       const int32_t* g_okoff, const uint8_t* pair_ok, int32_t n_groups, int32_t max_nc4,
                        int32_t mt, int32_t kt, int32_t row_stride, int32_t chan_stride, int32_t tap_stride,
                        int32_t tap_flip, hmvae_stream_t stream);
 
@@ -213,6 +219,13 @@ int hmvae_decode_tail_loss(const float* dec_out, const float* gt6d, const float*
 /* decode tail, inference: SoA decoder output -> AoS cont6d (B,T,24,6), R (B,T,24,3,3), pos (B,T,24,3) */
 int hmvae_decode_tail_fwd(const float* dec_out, const float* offsets, int32_t T, int32_t B, int32_t bp, float* c6,
                           float* R, float* pos, hmvae_stream_t stream);
+
+/* seq_two_hier_sa_vae.py:408-411 + the means of :425-434 in one launch: fixed-order sums of the MSE / KL block
+ * partials, then out = [total, kl, rec_6d, rec_rot, rec_pose, kl_shallow, kl_deep, 0] */
+int hmvae_vae_loss_finalize(const float* mse_partial, int32_t n_mse, const float* kl0_partial, int32_t n_kl0,
+                            const float* kld_partial, int32_t n_kld, float inv_n6, float inv_nR, float inv_nP,
+                            float inv_rows0, float inv_rowsd, float w6, float wR, float wP, float w_kl, float w_skl,
+                            float* out8, hmvae_stream_t stream);
 
 /* out[0..n_out) : fixed-order sums of partial[i*stride + k], scaled */
 int hmvae_finalize_sums(const float* partial, int32_t n_partial, int32_t stride, int32_t k, float scale, float* out,

@@ -65,10 +65,10 @@ def emu_gather(side, wp, src, dst, bias=None, leaky=False, accum=False, slope=0.
 
 def emu_wgrad(op, dy, x, dw):
     """dy, x: numpy [rows, bp]; writes dense dw (n_rows, n_chan, kt) at masked positions."""
-    g = op.fwd.g
+    g = op.wg
     ge = op.geom
     R = g.mt * 16
-    chan_rows, dz_rows = _np(op.fwd.chan_rows), _np(op.dz_rows)
+    chan_rows, dz_rows = _np(op.wg_chan_rows), _np(op.dz_rows)
     row_id = g.row_id.reshape(g.n_groups, R)
     n_rows, n_chan, kt = op.w_shape
     dwf = dw.reshape(n_rows, n_chan, kt)
