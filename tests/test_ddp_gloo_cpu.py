@@ -1,0 +1,115 @@
+"""world_size-2 `gloo` tests of the data-parallel path (hm_vae_amd/ddp.py + the engine's flat gradient bucket).
+
+No GPU: the per-rank gradients come from the CPU oracle; what is under test is the host logic that has to be right
+by construction on 8 GPUs — bucket layout, which tensors are left out of the collective in each phase, the mean
+all-reduce, parameter broadcast and batch sharding — and the identity it relies on (mean of equal-shard gradients ==
+full-batch gradient).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import load_cfg, offsets
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tag, phase2, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from oracle import hmvae_oracle as O
+    from hm_vae_amd import ddp
+    from hm_vae_amd.engine import VaeEngine
+    from hm_vae_amd.trainer_motion_vae import Trainer
+    r, w, _ = ddp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and ddp.is_distributed() and ddp.rank() == rank and ddp.world_size() == world
+    cfg = load_cfg(tag)
+    plan = O.Plan(cfg)
+    seeded = O.name_seeded_params(plan)
+    # every rank starts from different weights; broadcast must make them rank 0's
+    torch.manual_seed(100 + rank)
+    tr = Trainer(cfg)
+    params = [p for p in tr.model.parameters() if p.requires_grad]
+    ddp.broadcast_parameters(params)
+    chk = torch.stack([p.detach().double().sum() for p in params])
+    gathered = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(gathered, chk)
+    assert all(torch.equal(g, gathered[0]) for g in gathered)
+
+    B = 4
+    it = cfg["iteration_interval"] if phase2 else 0
+    full = O.synthetic_batch(B, cfg["train_seq_len"], seed=5)
+    eps_full = O.level_eps(plan, B, seed=6)
+    shard = ddp.shard_batch(full, rank, world)
+    n = B // world
+    eps_shard = [e.reshape(B, -1, e.shape[1])[rank * n:(rank + 1) * n].reshape(-1, e.shape[1]) for e in eps_full]
+    orc = O.OracleVAE(cfg, seeded, offsets=offsets())
+    orc.train_forward(shard, it, eps_shard)
+    # the engine plans its bucket on CPU (no kernels run); fill each live tensor's slice with this rank's gradient
+    eng = VaeEngine(cfg, dict(tr.model.named_parameters()), offsets(), "cpu")
+    order, offs, n1, n2, always, ph2, never = eng.grad_layout()
+    eng.assign_grads(phase2)
+    live = 0
+    for name, p in orc.trainable():
+        mine = eng.params[name]
+        if p.grad is None:
+            assert mine.grad is None, name
+            continue
+        assert mine.grad is not None, name
+        mine.grad.copy_(p.grad)
+        live += 1
+    assert live == (22 if phase2 else 20)
+    nfl = eng.active_grad_floats(phase2)
+    assert nfl == (n2 if phase2 else n1)
+    tail_before = eng.flat_grad[nfl:].clone()
+    ddp.all_reduce_mean_(eng.flat_grad[:nfl])
+    assert torch.equal(eng.flat_grad[nfl:], tail_before)          # tensors without gradient are not communicated
+    if rank == 0:
+        ref = O.OracleVAE(cfg, seeded, offsets=offsets())
+        ref.train_forward(full, it, eps_full)
+        worst = 0.0
+        for name, p in ref.trainable():
+            if p.grad is None:
+                continue
+            a = eng.params[name].grad.numpy().astype(np.float64)
+            b = p.grad.numpy().astype(np.float64)
+            worst = max(worst, float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)))
+        with open(os.path.join(out_dir, "result_%s_%d.txt" % (tag, int(phase2))), "w") as f:
+            f.write("%.3e" % worst)
+    # uneven shards are refused (the mean-of-means identity needs equal shards)
+    try:
+        ddp.shard_batch(tuple(t[:3] for t in full), rank, world)
+        raise AssertionError("expected ValueError")
+    except ValueError:
+        pass
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("phase2", [False, True])
+def test_two_rank_gradient_bucket_allreduce(tmp_path, phase2):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, "len8", phase2, str(tmp_path)), nprocs=2, join=True)
+    worst = float(open(os.path.join(str(tmp_path), "result_len8_%d.txt" % int(phase2))).read())
+    # mean of the two half-batch gradients == full-batch gradient, up to fp32 summation order
+    assert worst < 2e-5, worst
+
+
+def test_single_process_helpers_are_noops():
+    from hm_vae_amd import ddp
+    assert not ddp.is_distributed() and ddp.rank() == 0 and ddp.world_size() == 1
+    t = torch.arange(4.0)
+    assert ddp.all_reduce_mean_(t) is t and torch.equal(t, torch.arange(4.0))
+    ddp.broadcast_parameters([torch.zeros(3)])

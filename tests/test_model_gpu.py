@@ -223,3 +223,18 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     opt = torch.load(str(tmp_path / "optimizer.pt"), map_location="cpu", weights_only=True)["gen"]
     assert len(opt["param_groups"][0]["params"]) == 30
     assert len(opt["state"]) == 20          # 10 of the 30 tensors have no gradient in phase 1
+
+
+def test_train_cli_runs(dev, tmp_path):
+    """train_motion_vae.py keeps the reference's flags and loop: three iterations on synthetic batches."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "train_motion_vae.py"), "--config",
+           os.path.join(root, "configs", "len8_data_aug_hm_vae.yaml"), "--output_path", str(tmp_path), "--batch_size", "4",
+           "--max_iter", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Training: Total loss" in r.stdout and "Finish Training" in r.stdout
+    assert os.path.exists(os.path.join(str(tmp_path), "outputs", "len8_data_aug_hm_vae", "config.yaml"))
