@@ -101,8 +101,12 @@ def _merge_units(units, cap):
     return units
 
 
-def make_groups(joint_rows, joint_chans, kt, mt_choices=(1, 2, 3, 4)):
-    """joint_rows[j]: dense row ids owned by block j; joint_chans[j]: dense channel ids block j reads."""
+def make_groups(joint_rows, joint_chans, kt, mt_choices=(1,)):
+    """joint_rows[j]: dense row ids owned by block j; joint_chans[j]: dense channel ids block j reads.
+
+    Default: one 16-row tile per group.  Measured on MI355X at B=256 (tools/profile_layers.py with HMVAE_MT=1..4):
+    16-row groups win on every layer for the pipelined gather kernel — they give 3-4x more workgroups (the small-T
+    layers otherwise put ~1 workgroup on a CU) and never pay for a union channel list."""
     import os
     if os.environ.get("HMVAE_MT"):
         mt_choices = tuple(int(c) for c in os.environ["HMVAE_MT"].split(","))
