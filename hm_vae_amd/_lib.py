@@ -32,8 +32,8 @@ class Gemm2Desc(C.Structure):
     _fields_ = [("src", _ptr), ("dst", _ptr), ("wp", _ptr), ("bias", _ptr), ("bias_idx", _ptr), ("g_nc4", _ptr),
                 ("g_woff", _ptr), ("g_choff", _ptr), ("chan_rows", _ptr), ("dst_rows", _ptr), ("pb_off", _ptr),
                 ("pb_len", _ptr), ("items", _ptr), ("n_groups", _i32), ("mt", _i32), ("kt", _i32), ("n_pos", _i32),
-                ("bp", _i32), ("np", _i32), ("n_pblk", _i32), ("n_units", _i32), ("ksplit", _i32), ("wpos", _i32), ("max_items", _i32), ("max_nc4", _i32), ("src_ts", _i32),
-                ("dst_ts", _i32), ("flags", _i32), ("slope", _f32)]
+                ("bp", _i32), ("np", _i32), ("n_pblk", _i32), ("n_units", _i32), ("ksplit", _i32), ("xcd_mode", _i32), ("wpos", _i32), ("max_items", _i32), ("max_nc4", _i32), ("src_ts", _i32),
+                ("dst_ts", _i32), ("flags", _i32), ("slope", _f32), ("debug", _ptr)]
 
 
 class WgradDesc(C.Structure):

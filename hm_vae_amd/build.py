@@ -20,6 +20,9 @@ def _newer(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
+    extra = ["-DHMVAE_STAMP"] if os.environ.get("HMVAE_STAMP") else []      # diagnostic build (tools/stamp_gemm.py)
+    if extra:
+        force = True
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(ROOT, "include", "hmvae.h")]
     if not force and not _newer(LIB_PATH, deps):
@@ -30,7 +33,7 @@ def build(force=False, verbose=True):
         o = os.path.join(LIB_DIR, os.path.basename(s).replace(".hip", ".o"))
         if force or _newer(o, [s, deps[-1]]):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
-                   "-c", s, "-o", o]
+                   "-c", s, "-o", o] + extra
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -22,6 +22,18 @@ constexpr int MAX_ITEMS = 256;      // items per position block (host checks)
 constexpr int MAX_C4 = 512;         // 4-channel steps per group (host checks)
 constexpr int TABLE_INTS = 2 * MAX_ITEMS + 4 * MAX_C4;
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#ifdef HMVAE_STAMP
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        if (d.debug && lane == 0) {                                                                \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            d.debug[((size_t)blockIdx.x * nwaves + wid) * 4 + (i)] = t_;                           \
+        }                                                                                          \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
 
 template <int MT, int CW>
 struct VStage {          // operands of one item, in flight between its loads and its MFMAs
@@ -35,7 +47,7 @@ struct SStage {          // the item's table entries, read from the LDS copies o
 };
 
 template <int MT, int CW, int DEPTH>
-__global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
+__global__ __launch_bounds__(512) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int nwaves = blockDim.x >> 6;
     const int wpos = d.wpos;                         // 1: waves split K;  4: waves take 4 neighbouring position blocks
@@ -44,11 +56,22 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
     const int u = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per || u >= d.n_units) return;
     const int n_ct = d.bp / (64 * CW);
-    const int ct = u % n_ct;
-    const int r0 = u / n_ct;
     const int n_pq = (d.n_pblk + wpos - 1) / wpos;
-    const int pq = r0 % n_pq;
-    const int g = r0 / n_pq;
+    int ct, pq, g;
+    if (d.xcd_mode == 0) {
+        // group-major ranges: an XCD's L2 only sees the packed weights of its own few groups (weight-heavy layers)
+        ct = u % n_ct;
+        const int r0 = u / n_ct;
+        pq = r0 % n_pq;
+        g = r0 / n_pq;
+    } else {
+        // position-major ranges, group fastest: every XCD gets the same mix of (unequally long) groups, and only a
+        // slice of the positions, i.e. of the activation rows (layers whose weights fit in every L2)
+        g = u % d.n_groups;
+        const int r0 = u / d.n_groups;
+        ct = r0 % n_ct;
+        pq = r0 / n_ct;
+    }
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // scalar: keeps the K loop uniform
     const int wave = wpos > 1 ? 0 : wid;             // index inside the K split
@@ -57,6 +80,7 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
     const int kk = lane >> 4;
     const int n = lane & 15;
 
+    STAMP(0);
     const int nc4 = d.g_nc4[g];
     const int choff = d.g_choff[g];
     const int nitems = live ? d.pb_len[pb] : 0;
@@ -99,6 +123,7 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
 
     const int n_mine = wave < nc4 ? (nc4 - wave + nw - 1) / nw : 0;
     const int total = n_mine * nitems;
+    STAMP(1);
     if (total > 0) {
         // Software pipeline, three stages per item:  S (scalar table reads) -> V (vector operand loads) -> M (MFMAs).
         // S runs 3 items ahead of M, V runs 2 items ahead.  The steady-state loop body is branch-free straight-line
@@ -186,6 +211,7 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
         flush();
     }
 
+    STAMP(2);
     const int p = pb;
     if (!live) {
         if (nw > 1) {          // keep the barriers of the K-split epilogue matched
@@ -219,6 +245,7 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
                     if (d.flags & HMVAE_FLAG_ACCUM) s += *(const f32x4*)dp;
                     *(f32x4*)dp = s;
                 }
+        STAMP(3);
         return;
     }
     // K split over the waves: sum through LDS, one 64-column unit at a time
@@ -256,6 +283,7 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
             *(f32x4*)dp = s;
         }
     }
+    STAMP(3);
 }
 
 template <int MT, int CW>
@@ -274,7 +302,7 @@ extern "C" int hmvae_gather_gemm_v2(const hmvae_gemm2_desc* desc, hmvae_stream_t
     if (!desc || !desc->src || !desc->dst || !desc->wp || !desc->items || (desc->bias && !desc->bias_idx)) return HMVAE_ERR_ARG;
     if (desc->bp <= 0 || (desc->bp & 63) || desc->n_groups <= 0 || desc->n_pos <= 0 || desc->kt <= 0 || desc->kt > 254)
         return HMVAE_ERR_ARG;
-    if (desc->ksplit != 1 && desc->ksplit != 2 && desc->ksplit != 4) return HMVAE_ERR_ARG;
+    if (desc->ksplit != 1 && desc->ksplit != 2 && desc->ksplit != 4 && desc->ksplit != 8) return HMVAE_ERR_ARG;
     if (desc->max_items <= 0 || desc->max_items > MAX_ITEMS || desc->max_nc4 <= 0 || desc->max_nc4 > MAX_C4) return HMVAE_ERR_UNSUPPORTED;
     const int cw = desc->np;            // 64-column units per wave (1, 2 or 4)
     if (cw != 1 && cw != 2 && cw != 4) return HMVAE_ERR_ARG;

@@ -17,6 +17,9 @@ from . import planner as P
 import os as _os
 
 USE_V2 = _os.environ.get("HMVAE_GEMM", "v2") != "v1"
+AUTOTUNE = _os.environ.get("HMVAE_AUTOTUNE", "1") != "0"
+XCD_MODE = None if _os.environ.get("HMVAE_XCD") is None else int(_os.environ["HMVAE_XCD"])
+DEBUG_BUF = None          # diagnostic builds only (tools/stamp_gemm.py)
 
 
 def pad_batch(b):
@@ -56,7 +59,8 @@ class _Side:
         p_off, p_len, flat = P.flatten_pairs(pairs)
         self.pairs_host = pairs
         self._items = {}
-        self.tune = None                      # (np, ksplit) override for experiments
+        self._tuned = {}
+        self.tune = None                      # (cw, ksplit) override for experiments
         self.n_pos = len(pairs)
         self.p_off, self.p_len, self.pairs = _dev(p_off, device), _dev(p_len, device), _dev(flat, device)
         self.src_ts, self.dst_ts = int(src_ts), int(dst_ts)
@@ -79,14 +83,57 @@ class _Side:
                                 int(pb_len.max()))
         return self._items[np_]
 
+    def xcd_mode(self):
+        """Small packed weights (they fit in every XCD's 4 MB L2 next to the activations): balance the unequal groups
+        over the XCDs and give each XCD a slice of the positions.  Big (dense) weights: keep each XCD on its own groups."""
+        if XCD_MODE is not None:
+            return XCD_MODE
+        return 1 if self.g.packed_size * 4 <= (8 << 20) else 0
+
     def choose(self, bp):
         if self.tune is not None:
             return self.tune
+        if bp in self._tuned:
+            return self._tuned[bp]
         g = self.g
         return P.pick_np_ksplit(g.mt, g.n_groups, self.n_pos, bp // 64, float(g.g_nc4.mean()))
 
+    def autotune(self, src, dst, bp, bias, flags, slope):
+        """Measure, don't guess: time the (column units per wave, K split) candidates once per batch size on the real
+        operands (HIP events, scratch destination) and keep the fastest.  Runs during warm-up, never inside a graph
+        capture.  HMVAE_AUTOTUNE=0 falls back to the static heuristic."""
+        if bp in self._tuned or self.tune is not None or not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+            return
+        g = self.g
+        scratch = torch.empty_like(dst)
+        fl = int(flags) & ~_lib.FLAG_ACCUM
+        best = None
+        for cw in (1, 2, 4):
+            if g.mt * cw > 4 or int(bp) % (64 * cw):
+                continue
+            for ks in (2, 4, 8):
+                if ks > 1 and float(g.g_nc4.mean()) / ks < 1.0:
+                    continue
+                self.tune = (cw, ks)
+                for _ in range(2):
+                    self.run_v2(src, scratch, bp, bias, fl, slope)
+                evs = []
+                for _ in range(4):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    self.run_v2(src, scratch, bp, bias, fl, slope)
+                    b.record()
+                    evs.append((a, b))
+                torch.cuda.synchronize()
+                t = sorted(x.elapsed_time(y) for x, y in evs)[1]
+                if best is None or t < best[0]:
+                    best = (t, cw, ks)
+        self.tune = None
+        self._tuned[bp] = (best[1], best[2])
+
     def run(self, src, dst, bp, bias=None, flags=0, slope=0.2):
         if USE_V2:
+            self.autotune(src, dst, bp, bias, flags, slope)
             return self.run_v2(src, dst, bp, bias, flags, slope)
         return self.run_v1(src, dst, bp, bias, flags, slope)
 
@@ -104,9 +151,9 @@ class _Side:
         d = _lib.Gemm2Desc(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(self.wp), _lib.ptr(bias), _lib.ptr(self.bias_idx),
                            _lib.ptr(self.g_nc4), _lib.ptr(self.g_woff), _lib.ptr(self.g_choff), _lib.ptr(self.chan_rows),
                            _lib.ptr(self.dst_rows), _lib.ptr(pb_off), _lib.ptr(pb_len), _lib.ptr(items), g.n_groups, g.mt,
-                           g.kt, self.n_pos, int(bp), np_, n_pblk, n_units, ks, wpos, max_items, int(g.g_nc4.max()), self.src_ts,
+                           g.kt, self.n_pos, int(bp), np_, n_pblk, n_units, ks, self.xcd_mode(), wpos, max_items, int(g.g_nc4.max()), self.src_ts,
                            self.dst_ts, int(flags),
-                           float(slope))
+                           float(slope), _lib.ptr(DEBUG_BUF))
         _lib.check(lib.hmvae_gather_gemm_v2(C.byref(d), _lib.stream()), "gather_gemm_v2")
 
     def run_v1(self, src, dst, bp, bias=None, flags=0, slope=0.2):

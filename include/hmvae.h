@@ -90,11 +90,13 @@ typedef struct {
     const int32_t* items;    /* pairs of int32: q, taps packed 8 bits per owned position */
     int32_t n_groups, mt, kt, n_pos, bp;
     int32_t np, n_pblk, n_units, ksplit;
+    int32_t xcd_mode;             /* 0: units dealt to XCDs in group-major ranges; 1: position-major ranges, group fastest */
     int32_t wpos;                 /* 1: the workgroup's waves split K (ksplit); 4: they take 4 neighbouring position blocks */
     int32_t max_items, max_nc4;   /* largest pb_len / g_nc4 (the kernel stages both tables in LDS: <= 256 / <= 512) */
     int32_t src_ts, dst_ts;
     int32_t flags;
     float slope;
+    uint64_t* debug;         /* NULL in production; a diagnostic build (-DHMVAE_STAMP) writes 4 s_memtime stamps per wave */
 } hmvae_gemm2_desc;
 
 int hmvae_gather_gemm_v2(const hmvae_gemm2_desc* desc, hmvae_stream_t stream);

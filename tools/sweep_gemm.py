@@ -35,7 +35,7 @@ for name, op in zip(names, convs):
         mt = side.g.mt
         res = []
         for np_ in {1: (1, 2, 4), 2: (1, 2), 3: (1,), 4: (1,)}[mt]:
-            for ks in (1, 2, 4):
+            for ks in (2, 4, 8):
                 side.tune = (np_, ks)
                 out.zero_()
                 side.run_v2(src, out, bp)
