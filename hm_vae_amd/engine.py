@@ -108,6 +108,13 @@ class VaeEngine:
         self._ws = {}
         self._bias_rows = {}
         self._flat = None
+        self._side = None
+        self._pack_stream = None
+        import os as _os
+        self.overlap = _os.environ.get("HMVAE_OVERLAP", "1") != "0"
+        self.n_side = int(_os.environ.get("HMVAE_SIDE_STREAMS", "2"))
+        self.pack_async = _os.environ.get("HMVAE_PACK_ASYNC", "0") == "1"
+        self._turn = 0
         self.flops_per_seq = self._count_flops()
 
     # ------------------------------------------------------------------------------------------
@@ -164,6 +171,8 @@ class VaeEngine:
         for op in self.enc_conv + self.dec_conv + self.enc_lin + list(self.dec_lin.values()):
             slab = max(slab, op.slab_floats(bp))
         w["slab"] = torch.empty(slab, device=dev)
+        for k in range(self.n_side):            # one slab per side stream: their weight-gradient kernels may overlap
+            w["slab%d" % k] = w["slab"] if k == 0 else torch.empty(slab, device=dev)
         self._ws[B] = w
         return w
 
@@ -231,16 +240,40 @@ class VaeEngine:
         _, _, n1, n2, *_ = self.grad_layout()
         return n2 if phase2 else n1
 
-    def pack_weights(self):
+    def _pack_list(self):
+        """(op, dense weight) in the order the step consumes them."""
         P = self.params
         enc_w, _, dconv = self.names()
         L = self.p.L
-        for i in range(L):
-            self.enc_conv[i].pack(P[enc_w[i]])
-            self.dec_conv[i].pack(P[dconv[i] + ".weight"])
-        for i in (0, L - 1):
-            self.enc_lin[i].pack(P["enc.latent_enc_layers.%d.weight" % i])
-            self.dec_lin[i].pack(P["dec.latent_dec_layers.%d.weight" % i])
+        lst = [(self.enc_conv[i], P[enc_w[i]]) for i in range(L)]
+        lst += [(self.enc_lin[i], P["enc.latent_enc_layers.%d.weight" % i]) for i in (0, L - 1)]
+        lst += [(self.dec_lin[i], P["dec.latent_dec_layers.%d.weight" % i]) for i in (0, L - 1)]
+        lst += [(self.dec_conv[i], P[dconv[i] + ".weight"]) for i in range(L)]
+        return lst
+
+    def pack_weights(self, side=True):
+        """Regather the dense weights into MFMA-fragment order (applies the neighbour mask, skeleton.py:96).
+        With `side`, the ~23 small memory-bound pack kernels run on their own stream, forward layouts first in layer
+        order and backward layouts after, each leaving an event its consumer waits on — so they hide under the
+        batch staging and the first convolutions instead of delaying them."""
+        lst = self._pack_list()
+        # measured: the per-layer events cost more than the overlap buys at B=256 (3.33 vs 3.03 ms/step), so the
+        # side-stream variant is opt-in
+        if not (side and self.overlap and self.pack_async):
+            for op, wt in lst:
+                op.pack(wt)
+            return
+        main = torch.cuda.current_stream()
+        if self._pack_stream is None:
+            self._pack_stream = torch.cuda.Stream(device=self.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._pack_stream.wait_event(ev)
+        with torch.cuda.stream(self._pack_stream):
+            for op, wt in lst:
+                op.pack_side(wt, "f")
+            for op, wt in reversed(lst):
+                op.pack_side(wt, "b")
 
     # ------------------------------------------------------------------------------------------
     # forward pieces
@@ -321,10 +354,48 @@ class VaeEngine:
         if backward:
             self._backward(w, phase2, eps, B, bp)
             self.assign_grads(phase2)
+        if self._pack_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._pack_stream)
         return ls
 
-    def _wgrad(self, op, dy, x, name, bp, w):
-        op.backward_weight(dy, x, self.grad_view(name), bp, w["slab"])
+    # ---- weight / bias gradients run on a side stream ----
+    # They only READ dY and the forward activations and write gradient slices nobody else touches, so they overlap
+    # with the backward-data chain of the following layers (two kernels that each leave SIMDs idle in their tails
+    # fill the chip together).  Fork = event on the main stream once dY is final; join = end of _backward.
+    def _fork(self):
+        if not self.overlap:
+            return None
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.n_side)]
+        self._turn = (self._turn + 1) % self.n_side
+        side = self._side[self._turn]
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        return torch.cuda.stream(side)
+
+    def _join(self):
+        if self.overlap and self._side is not None:
+            for s in self._side:
+                torch.cuda.current_stream().wait_stream(s)
+
+    def _wgrad(self, op, dy, x, name, bp, w, bias=None):
+        """bias: optional (src, grad_name, rows_key, base, n_out, rows_per_out, row_step) for the row-sum kernel."""
+        ctx = self._fork()
+        if ctx is None:
+            op.backward_weight(dy, x, self.grad_view(name), bp, w["slab"])
+            if bias is not None:
+                self._bias_grad(bias, bp)
+            return
+        with ctx:
+            op.backward_weight(dy, x, self.grad_view(name), bp, w["slab%d" % self._turn])
+            if bias is not None:
+                self._bias_grad(bias, bp)
+
+    def _bias_grad(self, b, bp):
+        src, gname, key, base, n_out, rows_per, step = b
+        ops.row_sums(src, self.grad_view(gname), self._rows(key, base, len(base)), n_out, rows_per, step, bp)
 
     def _backward(self, w, phase2, eps, B, bp):
         hp, p, L = self.hp, self.p, self.p.L
@@ -340,11 +411,11 @@ class VaeEngine:
                 else:
                     ops.leaky_bwd(dy, w["D%d" % i], dy, dy.numel())
             conv = self.dec_conv[i]
-            self._wgrad(conv, dy, w["U%d" % i], dconv[i] + ".weight", bp, w)
+            bias = None
             if p.dec_bias[i]:
                 base = (np.arange(p.dec_cout[i]) * t_conv).astype(np.int32)
-                ops.row_sums(dy, self.grad_view(dconv[i] + ".bias"), self._rows(("dconvb", i), base, len(base)),
-                             p.dec_cout[i], t_conv, 1, bp)
+                bias = (dy, dconv[i] + ".bias", ("dconvb", i), base, p.dec_cout[i], t_conv, 1)
+            self._wgrad(conv, dy, w["U%d" % i], dconv[i] + ".weight", bp, w, bias)
             conv.backward_data(dy, w["dU%d" % i], bp)
             dst = w["dH0"] if i == 0 else w["dD%d" % (i - 1)]
             self.dec_unpool[i].backward(w["dU%d" % i], dst, p.dec_ts[i], bp)
@@ -352,17 +423,16 @@ class VaeEngine:
         t_cat = p.dec_ts[L - 1]
         lin = self.dec_lin[L - 1]
         dcat = w["dD%d" % (L - 2)]
-        self._wgrad(lin, dcat, w["Z0"], "dec.latent_dec_layers.%d.weight" % (L - 1), bp, w)
         base = (np.arange(p.dec_feat[L - 1]) + self.cD * t_cat).astype(np.int32)
-        ops.row_sums(dcat, self.grad_view("dec.latent_dec_layers.%d.bias" % (L - 1)), self._rows("dlinb_last", base, len(base)),
-                     p.dec_feat[L - 1], p.edge_num[1], self.cat_edge_rows, bp)
+        self._wgrad(lin, dcat, w["Z0"], "dec.latent_dec_layers.%d.weight" % (L - 1), bp, w,
+                    (dcat, "dec.latent_dec_layers.%d.bias" % (L - 1), "dlinb_last", base, p.dec_feat[L - 1], p.edge_num[1],
+                     self.cat_edge_rows))
         if phase2:
             lin.backward_data(dcat, w["dZ0"], bp)
         lin = self.dec_lin[0]
-        self._wgrad(lin, w["dH0"], w["Z%d" % (L - 1)], "dec.latent_dec_layers.0.weight", bp, w)
         base = np.arange(p.dec_feat[0]).astype(np.int32)
-        ops.row_sums(w["dH0"], self.grad_view("dec.latent_dec_layers.0.bias"), self._rows("dlinb0", base, len(base)),
-                     p.dec_feat[0], p.edge_num[L], p.dec_feat[0], bp)
+        self._wgrad(lin, w["dH0"], w["Z%d" % (L - 1)], "dec.latent_dec_layers.0.weight", bp, w,
+                    (w["dH0"], "dec.latent_dec_layers.0.bias", "dlinb0", base, p.dec_feat[0], p.edge_num[L], p.dec_feat[0]))
         lin.backward_data(w["dH0"], w["dZ%d" % (L - 1)], bp)
         # ---------------- reparametrisation + KL ----------------
         k, d = p.edge_num[L], p.lat_dim[L - 1]
@@ -374,30 +444,27 @@ class VaeEngine:
         # ---------------- encoder ----------------
         i = L - 1
         lin = self.enc_lin[i]
-        self._wgrad(lin, w["dZD%d" % i], w["A%d" % i], "enc.latent_enc_layers.%d.weight" % i, bp, w)
         base = np.arange(2 * d).astype(np.int32)
-        ops.row_sums(w["dZD%d" % i], self.grad_view("enc.latent_enc_layers.%d.bias" % i), self._rows(("elinb", i), base, len(base)),
-                     2 * d, k, 2 * d, bp)
+        self._wgrad(lin, w["dZD%d" % i], w["A%d" % i], "enc.latent_enc_layers.%d.weight" % i, bp, w,
+                    (w["dZD%d" % i], "enc.latent_enc_layers.%d.bias" % i, ("elinb", i), base, 2 * d, k, 2 * d))
         lin.backward_data(w["dZD%d" % i], w["dA%d" % i], bp)
         for i in range(L - 1, -1, -1):
             if i == 0 and phase2:
                 lin = self.enc_lin[0]
                 k0, d0 = p.edge_num[1], p.lat_dim[0]
-                self._wgrad(lin, w["dZD0"], w["A0"], "enc.latent_enc_layers.0.weight", bp, w)
                 base = np.arange(2 * d0).astype(np.int32)
-                ops.row_sums(w["dZD0"], self.grad_view("enc.latent_enc_layers.0.bias"), self._rows(("elinb", 0), base, len(base)),
-                             2 * d0, k0, 2 * d0, bp)
+                self._wgrad(lin, w["dZD0"], w["A0"], "enc.latent_enc_layers.0.weight", bp, w,
+                            (w["dZD0"], "enc.latent_enc_layers.0.bias", ("elinb", 0), base, 2 * d0, k0, 2 * d0))
                 lin.backward_data(w["dZD0"], w["dA0"], bp, accumulate=True)
             t = p.tsteps[i + 1]
             self.enc_pool[i].backward(w["dA%d" % i], w["A%d" % i], w["dY%d" % i], t, bp)
             conv = self.enc_conv[i]
             x = w["X0"] if i == 0 else w["A%d" % (i - 1)]
-            self._wgrad(conv, w["dY%d" % i], x, enc_w[i], bp, w)
             base = (np.arange(p.enc_cout[i]) * t).astype(np.int32)
-            ops.row_sums(w["dY%d" % i], self.grad_view(enc_b[i]), self._rows(("econvb", i), base, len(base)), p.enc_cout[i], t,
-                         1, bp)
+            self._wgrad(conv, w["dY%d" % i], x, enc_w[i], bp, w, (w["dY%d" % i], enc_b[i], ("econvb", i), base, p.enc_cout[i], t, 1))
             if i > 0:
                 conv.backward_data(w["dY%d" % i], w["dA%d" % (i - 1)], bp)
+        self._join()
 
     # ------------------------------------------------------------------------------------------
     # inference pieces (test()/gen_seq()/_decode)
@@ -413,7 +480,7 @@ class VaeEngine:
         B = z0.shape[0]
         w = self.workspace(B)
         if repack:
-            self.pack_weights()
+            self.pack_weights(side=False)
         self.load_latents(w, z0, z_deep)
         self.decode_feats(w)
         T = self.p.T
@@ -429,7 +496,7 @@ class VaeEngine:
         w = self.workspace(B)
         bp, L, p = w["bp"], self.p.L, self.p
         if repack:
-            self.pack_weights()
+            self.pack_weights(side=False)
             for i in range(1, L - 1):
                 self.enc_lin[i].pack(self.params["enc.latent_enc_layers.%d.weight" % i])
         ops.aos_to_soa(r6.contiguous(), w["X0"], B, T, 144, bp)
