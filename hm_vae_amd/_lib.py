@@ -49,6 +49,12 @@ class WreduceDesc(C.Structure):
                 ("n_tiles", _i32), ("mt", _i32), ("kt", _i32), ("n_split", _i32), ("row_stride", _i32), ("chan_stride", _i32), ("accumulate", _i32)]
 
 
+class PackOp(C.Structure):
+    _fields_ = [("dense", _ptr), ("packed", _ptr), ("g_nc4", _ptr), ("g_woff", _ptr), ("g_choff", _ptr), ("chan_id", _ptr),
+                ("row_id", _ptr), ("g_okoff", _ptr), ("pair_ok", _ptr), ("n_groups", _i32), ("max_nc4", _i32), ("mt", _i32),
+                ("kt", _i32), ("row_stride", _i32), ("chan_stride", _i32), ("tap_stride", _i32), ("block_start", _i32)]
+
+
 class AdamTensor(C.Structure):
     _fields_ = [("p", _ptr), ("g", _ptr), ("m", _ptr), ("v", _ptr), ("n", _i64)]
 
@@ -66,6 +72,7 @@ _SIGS = {
     "hmvae_wgrad_gemm": ([C.POINTER(WgradDesc), _ptr], _i32),
     "hmvae_wgrad_reduce": ([C.POINTER(WreduceDesc), _ptr], _i32),
     "hmvae_pack_weights": ([_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
+    "hmvae_pack_weights_multi": ([_ptr, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_pool_leaky_fwd": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),
     "hmvae_pool_leaky_bwd": ([_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),
     "hmvae_upsample_unpool_fwd": ([_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),

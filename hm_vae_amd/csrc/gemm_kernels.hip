@@ -438,33 +438,47 @@ extern "C" int hmvae_wgrad_reduce(const hmvae_wreduce_desc* desc, hmvae_stream_t
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }
 
-// One workgroup per (group, 4-channel step): the 64 (kk, m) lanes each own one (row, channel) pair and walk its taps,
-// so the ids / mask are looked up once per lane and the kt taps of a pair (contiguous in the dense tensor in the
-// forward layout) are read by one lane back to back.  Writes are whole 256-byte MFMA fragments.
+// One workgroup per (group, 4-channel step).  Reads walk the dense tensor in its own memory order (taps fastest, then
+// whichever of row/channel has the smaller stride), land in an LDS image of the packed chunk, and leave as whole
+// 256-byte MFMA fragments: both sides of the transposition are coalesced.
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ dense, float* __restrict__ packed,
                                                    const int* __restrict__ g_nc4, const int* __restrict__ g_woff,
                                                    const int* __restrict__ g_choff, const int* __restrict__ chan_id,
                                                    const int* __restrict__ row_id, const int* __restrict__ g_okoff,
                                                    const unsigned char* __restrict__ pair_ok, int mt, int kt, int row_stride,
                                                    int chan_stride, int tap_stride, int tap_flip) {
+    extern __shared__ float img[];                    // [kt][mt][64]
     const int g = blockIdx.y;
     const int c4 = blockIdx.x;
     const int nc4 = g_nc4[g];
     if (c4 >= nc4) return;
-    const int l = threadIdx.x & 63;
-    const int sub = threadIdx.x >> 6;
-    const int kk = l >> 4, m = l & 15;
-    const int cid = chan_id[g_choff[g] + c4 * 4 + kk];
-    float* out = packed + g_woff[g] + (size_t)c4 * kt * mt * 64 + l;
-    for (int m_t = 0; m_t < mt; ++m_t) {
-        const int rid = row_id[g * (mt * 16) + m_t * 16 + m];
-        const bool ok = rid >= 0 && cid >= 0 && pair_ok[g_okoff[g] + (m_t * 16 + m) * (nc4 * 4) + c4 * 4 + kk];
+    const int rows = mt * 16;
+    const bool chan_inner = chan_stride < row_stride;  // forward layout: channels of a row are adjacent
+    // one (row, channel) pair per thread (rows*4 <= 256), its kt taps read back to back: no index arithmetic per element
+    const int ab = threadIdx.x;
+    if (ab < rows * 4) {
+        int r, kk;
+        if (chan_inner) {
+            kk = ab & 3;
+            r = ab >> 2;
+        } else {
+            r = ab % rows;
+            kk = ab / rows;
+        }
+        const int rid = row_id[g * rows + r];
+        const int cid = chan_id[g_choff[g] + c4 * 4 + kk];
+        const bool ok = rid >= 0 && cid >= 0 && pair_ok[g_okoff[g] + r * (nc4 * 4) + c4 * 4 + kk];
         const float* src = dense + (ok ? (size_t)rid * row_stride + (size_t)cid * chan_stride : 0);
-        for (int tap = sub; tap < kt; tap += 4) {
+        float* dsti = img + (r >> 4) * 64 + kk * 16 + (r & 15);
+        for (int tap = 0; tap < kt; ++tap) {
             const int td = tap_flip ? (kt - 1 - tap) : tap;
-            out[(size_t)(tap * mt + m_t) * 64] = ok ? src[(size_t)td * tap_stride] : 0.f;
+            dsti[tap * mt * 64] = ok ? src[(size_t)td * tap_stride] : 0.f;
         }
     }
+    __syncthreads();
+    float* out = packed + g_woff[g] + (size_t)c4 * kt * mt * 64;
+    const int n = kt * mt * 64;
+    for (int i = threadIdx.x; i < n; i += 256) out[i] = img[i];
 }
 
 extern "C" int hmvae_pack_weights(const float* dense, float* packed, const int32_t* g_nc4, const int32_t* g_woff,
@@ -475,7 +489,57 @@ extern "C" int hmvae_pack_weights(const float* dense, float* packed, const int32
     if (!dense || !packed || !g_okoff || !pair_ok || n_groups <= 0 || max_nc4 <= 0 || mt < 1 || mt > 4 || kt <= 0)
         return HMVAE_ERR_ARG;
     dim3 grid((unsigned)max_nc4, (unsigned)n_groups), block(256);
-    hipLaunchKernelGGL(pack_kernel, grid, block, 0, (hipStream_t)stream, dense, packed, g_nc4, g_woff, g_choff, chan_id,
+    const size_t lds = (size_t)kt * mt * 64 * sizeof(float);
+    if (lds > 64 * 1024) return HMVAE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pack_kernel, grid, block, lds, (hipStream_t)stream, dense, packed, g_nc4, g_woff, g_choff, chan_id,
                        row_id, g_okoff, pair_ok, mt, kt, row_stride, chan_stride, tap_stride, tap_flip);
+    return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+}
+
+
+// ---- every pack of the model in one launch (23 launches of 4-15 us each were mostly launch floor) ----
+__global__ __launch_bounds__(256) void pack_multi_kernel(const hmvae_pack_op* __restrict__ ops, int n_ops) {
+    extern __shared__ float img[];
+    int oi = 0;
+    for (int i = 1; i < n_ops; ++i)
+        if ((int)blockIdx.x >= ops[i].block_start) oi = i;          // uniform scan over <= a few dozen entries
+    const hmvae_pack_op o = ops[oi];
+    const int local = blockIdx.x - o.block_start;
+    const int g = local / o.max_nc4;
+    const int c4 = local - g * o.max_nc4;
+    const int nc4 = o.g_nc4[g];
+    if (c4 >= nc4) return;
+    const int mt = o.mt, kt = o.kt;
+    const int rows = mt * 16;
+    const bool chan_inner = o.chan_stride < o.row_stride;
+    const int ab = threadIdx.x;
+    if (ab < rows * 4) {
+        int r, kk;
+        if (chan_inner) {
+            kk = ab & 3;
+            r = ab >> 2;
+        } else {
+            r = ab % rows;
+            kk = ab / rows;
+        }
+        const int rid = o.row_id[g * rows + r];
+        const int cid = o.chan_id[o.g_choff[g] + c4 * 4 + kk];
+        const bool ok = rid >= 0 && cid >= 0 && o.pair_ok[o.g_okoff[g] + r * (nc4 * 4) + c4 * 4 + kk];
+        const float* src = o.dense + (ok ? (size_t)rid * o.row_stride + (size_t)cid * o.chan_stride : 0);
+        float* dsti = img + (r >> 4) * 64 + kk * 16 + (r & 15);
+        for (int tap = 0; tap < kt; ++tap) dsti[tap * mt * 64] = ok ? src[(size_t)tap * o.tap_stride] : 0.f;
+    }
+    __syncthreads();
+    float* out = o.packed + o.g_woff[g] + (size_t)c4 * kt * mt * 64;
+    const int n = kt * mt * 64;
+    for (int i = threadIdx.x; i < n; i += 256) out[i] = img[i];
+}
+
+extern "C" int hmvae_pack_weights_multi(const hmvae_pack_op* ops_dev, int32_t n_ops, int32_t total_blocks,
+                                        int32_t max_kt_mt, hmvae_stream_t stream) {
+    if (!ops_dev || n_ops <= 0 || total_blocks <= 0 || max_kt_mt <= 0) return HMVAE_ERR_ARG;
+    const size_t lds = (size_t)max_kt_mt * 64 * sizeof(float);
+    if (lds > 64 * 1024) return HMVAE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), lds, (hipStream_t)stream, ops_dev, n_ops);
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }

@@ -76,6 +76,14 @@ class _Side:
                                           _lib.ptr(self.g_okoff), _lib.ptr(self.pair_ok), g.n_groups, int(g.g_nc4.max()),
                                           g.mt, g.kt, rs, cs, ts, 0, _lib.stream()), "pack_weights")
 
+    def pack_op(self, dense, block_start):
+        """Descriptor for hmvae_pack_weights_multi."""
+        g = self.g
+        rs, cs, ts = self.strides
+        return _lib.PackOp(_lib.ptr(dense), _lib.ptr(self.wp), _lib.ptr(self.g_nc4), _lib.ptr(self.g_woff),
+                           _lib.ptr(self.g_choff), _lib.ptr(self.chan_id), _lib.ptr(self.row_id), _lib.ptr(self.g_okoff),
+                           _lib.ptr(self.pair_ok), g.n_groups, int(g.g_nc4.max()), g.mt, g.kt, rs, cs, ts, int(block_start))
+
     def items_for(self, np_):
         if np_ not in self._items:
             pb_off, pb_len, items = P.build_items(self.pairs_host, np_)
@@ -503,3 +511,27 @@ def vae_loss_finalize(mse_partial, kl0_partial, kld_partial, inv_n6, inv_nR, inv
                                                    kl0_partial.numel(), _lib.ptr(kld_partial), kld_partial.numel(),
                                                    inv_n6, inv_nR, inv_nP, inv_rows0, inv_rowsd, w6, wR, wP, w_kl, w_skl,
                                                    _lib.ptr(out8), _lib.stream()), "vae_loss_finalize")
+
+
+class MultiPack:
+    """All weight packs of a model as one launch; the descriptor table is rebuilt only if a tensor moved."""
+
+    def __init__(self, device):
+        self.device = device
+        self.key = None
+        self.table = None
+
+    def run(self, sides_and_weights):
+        key = tuple((id(s), w.data_ptr()) for s, w in sides_and_weights)
+        if key != self.key:
+            arr = (_lib.PackOp * len(sides_and_weights))()
+            start = 0
+            kmax = 1
+            for i, (s, w) in enumerate(sides_and_weights):
+                arr[i] = s.pack_op(w, start)
+                start += s.g.n_groups * int(s.g.g_nc4.max())
+                kmax = max(kmax, s.g.kt * s.g.mt)
+            self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            self.n_ops, self.total, self.kmax, self.key = len(sides_and_weights), start, kmax, key
+        _lib.check(_lib.load().hmvae_pack_weights_multi(self.table.data_ptr(), self.n_ops, self.total, self.kmax,
+                                                        _lib.stream()), "pack_weights_multi")

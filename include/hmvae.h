@@ -158,6 +158,25 @@ int hmvae_pack_weights(const float* dense, float* packed, const int32_t* g_nc4, 
                        int32_t mt, int32_t kt, int32_t row_stride, int32_t chan_stride, int32_t tap_stride,
                        int32_t tap_flip, hmvae_stream_t stream);
 
+/* All of a model's weight packs in ONE launch: `ops_dev` is a device array of n_ops descriptors whose block_start
+ * fields are the exclusive prefix sum of n_groups*max_nc4 (one workgroup per (group, 4-channel step)). */
+typedef struct {
+    const float* dense;
+    float* packed;
+    const int32_t* g_nc4;
+    const int32_t* g_woff;
+    const int32_t* g_choff;
+    const int32_t* chan_id;
+    const int32_t* row_id;
+    const int32_t* g_okoff;
+    const uint8_t* pair_ok;
+    int32_t n_groups, max_nc4, mt, kt;
+    int32_t row_stride, chan_stride, tap_stride, block_start;
+} hmvae_pack_op;
+
+int hmvae_pack_weights_multi(const hmvae_pack_op* ops_dev, int32_t n_ops, int32_t total_blocks, int32_t max_kt_mt,
+                             hmvae_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Element-wise / reduction kernels on SoA activations
  * ------------------------------------------------------------------------------------------------ */
