@@ -55,6 +55,11 @@ class PackOp(C.Structure):
                 ("kt", _i32), ("row_stride", _i32), ("chan_stride", _i32), ("tap_stride", _i32), ("block_start", _i32)]
 
 
+class RowsumOp(C.Structure):
+    _fields_ = [("src", _ptr), ("dst", _ptr), ("rows", _ptr), ("n_out", _i32), ("rows_per_out", _i32), ("row_step", _i32),
+                ("n_cols", _i32), ("accumulate", _i32), ("block_start", _i32)]
+
+
 class AdamTensor(C.Structure):
     _fields_ = [("p", _ptr), ("g", _ptr), ("m", _ptr), ("v", _ptr), ("n", _i64)]
 
@@ -72,6 +77,8 @@ _SIGS = {
     "hmvae_wgrad_gemm": ([C.POINTER(WgradDesc), _ptr], _i32),
     "hmvae_wgrad_reduce": ([C.POINTER(WreduceDesc), _ptr], _i32),
     "hmvae_pack_weights": ([_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
+    "hmvae_wgrad_reduce_multi": ([_ptr, _ptr, _i32, _i32, _ptr], _i32),
+    "hmvae_row_sums_multi": ([_ptr, _i32, _i32, _ptr], _i32),
     "hmvae_pack_weights_multi": ([_ptr, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_pool_leaky_fwd": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),
     "hmvae_pool_leaky_bwd": ([_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),

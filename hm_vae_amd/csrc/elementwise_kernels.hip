@@ -250,6 +250,35 @@ extern "C" int hmvae_row_sums(const float* src, float* dst, const int32_t* rows,
     return LAUNCH_OK();
 }
 
+__global__ __launch_bounds__(256) void row_sums_multi_kernel(const hmvae_rowsum_op* __restrict__ ops, int n_ops) {
+    __shared__ float sh[4];
+    int oi = 0;
+    for (int i = 1; i < n_ops; ++i)
+        if ((int)blockIdx.x >= ops[i].block_start) oi = i;
+    const hmvae_rowsum_op op = ops[oi];
+    const int o = blockIdx.x - op.block_start;
+    if (o >= op.n_out) return;
+    const int base = op.rows[o];
+    float s = 0.f;
+    const int nq = op.n_cols >> 2;
+    for (int k = 0; k < op.rows_per_out; ++k) {
+        const f32x4* p = (const f32x4*)(op.src + (size_t)(base + k * op.row_step) * op.n_cols);
+        for (int q = threadIdx.x; q < nq; q += 256) {
+            const f32x4 v = p[q];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    }
+    const float tot = block_sum256(s, sh);
+    if (threadIdx.x == 0) op.dst[o] = op.accumulate ? op.dst[o] + tot : tot;
+}
+
+extern "C" int hmvae_row_sums_multi(const hmvae_rowsum_op* ops_dev, int32_t n_ops, int32_t total_blocks,
+                                    hmvae_stream_t stream) {
+    if (!ops_dev || n_ops <= 0 || total_blocks <= 0) return HMVAE_ERR_ARG;
+    hipLaunchKernelGGL(row_sums_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, ops_dev, n_ops);
+    return LAUNCH_OK();
+}
+
 // ---------------- AoS (B,T,C) <-> SoA (C,T,Bp) ----------------
 __global__ __launch_bounds__(256) void aos_to_soa_kernel(const float* __restrict__ aos, float* __restrict__ soa, int B,
                                                           int T, int C, int bp) {

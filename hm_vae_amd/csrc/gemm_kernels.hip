@@ -429,6 +429,49 @@ __global__ __launch_bounds__(256) void wreduce_kernel(hmvae_wreduce_desc d) {
     }
 }
 
+__device__ __forceinline__ void wreduce_body(const hmvae_wreduce_desc& d, int blk, int nblk) {
+    const int rows = d.mt * 16;
+    const long long per_tile = (long long)rows * 64;
+    const long long total = per_tile * d.n_tiles;
+    for (long long idx = (long long)blk * 256 + threadIdx.x; idx < total; idx += (long long)nblk * 256) {
+        const int tile = (int)(idx / per_tile);
+        const int rem = (int)(idx - (long long)tile * per_tile);
+        const int row = rem >> 6, col = rem & 63;
+        const int g = d.tile_g[tile];
+        const int gc = d.tile_col0[tile] + col;
+        if (gc >= d.g_ncols[g]) continue;
+        const int rid = d.row_id[g * rows + row];
+        if (rid < 0) continue;
+        const int c = gc / d.kt;
+        const int tap = gc - c * d.kt;
+        const int cid = d.chan_id[d.g_choff[g] + c];
+        if (cid < 0) continue;
+        if (!d.pair_ok[d.g_okoff[g] + row * (d.g_nc4[g] * 4) + c]) continue;
+        float s = 0.f;
+        for (int sp = 0; sp < d.n_split; ++sp) s += d.slab[((size_t)sp * d.n_tiles + tile) * per_tile + rem];
+        float* o = d.dense + (size_t)rid * d.row_stride + (size_t)cid * d.chan_stride + tap;
+        if (d.accumulate) s += *o;
+        *o = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void wreduce_multi_kernel(const hmvae_wreduce_desc* __restrict__ descs,
+                                                            const int* __restrict__ block_start, int n_ops) {
+    int oi = 0;
+    for (int i = 1; i < n_ops; ++i)
+        if ((int)blockIdx.x >= block_start[i]) oi = i;
+    const hmvae_wreduce_desc d = descs[oi];
+    wreduce_body(d, blockIdx.x - block_start[oi], block_start[oi + 1] - block_start[oi]);
+}
+
+extern "C" int hmvae_wgrad_reduce_multi(const hmvae_wreduce_desc* descs_dev, const int32_t* block_start_dev, int32_t n_ops,
+                                        int32_t total_blocks, hmvae_stream_t stream) {
+    if (!descs_dev || !block_start_dev || n_ops <= 0 || total_blocks <= 0) return HMVAE_ERR_ARG;
+    hipLaunchKernelGGL(wreduce_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev,
+                       block_start_dev, n_ops);
+    return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+}
+
 extern "C" int hmvae_wgrad_reduce(const hmvae_wreduce_desc* desc, hmvae_stream_t stream) {
     if (!desc || !desc->slab || !desc->dense || !desc->pair_ok || desc->n_tiles <= 0) return HMVAE_ERR_ARG;
     const long long total = (long long)desc->n_tiles * desc->mt * 16 * 64;

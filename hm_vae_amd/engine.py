@@ -8,10 +8,17 @@ fp32 buffer (the DDP bucket), and the whole sequence is capturable in a hipGraph
 
 Buffers are "SoA": [rows][Bp], row = channel*T + t, batch innermost, Bp = batch rounded up to 64.
 """
+import contextlib
+import os as _os0
+
 import numpy as np
 import torch
 
 from . import _lib, ops, topology
+
+# 1: all slab->gradient reductions and bias sums as two launches after the backward chain (fewer launches, but they
+# then sit on the critical path; measured slower than overlapping them on the side streams)
+MULTI_REDUCE = _os0.environ.get("HMVAE_MULTI_REDUCE", "0") == "1"
 
 
 class VaePlan:
@@ -111,6 +118,7 @@ class VaeEngine:
         self._side = None
         self._pack_stream = None
         self._multipack = None
+        self._multired = None
         import os as _os
         self.overlap = _os.environ.get("HMVAE_OVERLAP", "1") != "0"
         self.n_side = int(_os.environ.get("HMVAE_SIDE_STREAMS", "2"))
@@ -168,12 +176,18 @@ class VaeEngine:
             w["D%d" % i], w["dD%d" % i] = buf(rows), buf(rows)
         w["MSEP"] = torch.zeros((bp // 64) * T0, 3, device=dev)
         w["losses"] = torch.zeros(8, device=dev)
-        slab = 1
-        for op in self.enc_conv + self.dec_conv + self.enc_lin + list(self.dec_lin.values()):
-            slab = max(slab, op.slab_floats(bp))
-        w["slab"] = torch.empty(slab, device=dev)
-        for k in range(self.n_side):            # one slab per side stream: their weight-gradient kernels may overlap
-            w["slab%d" % k] = w["slab"] if k == 0 else torch.empty(slab, device=dev)
+        # one slab per weight tensor: the weight-gradient GEMMs run on side streams and are all reduced together at the
+        # end of the backward pass (one launch)
+        all_ops = self.enc_conv + self.dec_conv + self.enc_lin + list(self.dec_lin.values())
+        tot = sum(op.slab_floats(bp) for op in all_ops)
+        big = torch.empty(max(tot, 1), device=dev)
+        o = 0
+        w["slabs"] = {}
+        for op in all_ops:
+            n = op.slab_floats(bp)
+            w["slabs"][id(op)] = big[o:o + n]
+            o += n
+        w["slab"] = big
         self._ws[B] = w
         return w
 
@@ -389,23 +403,27 @@ class VaeEngine:
 
     def _wgrad(self, op, dy, x, name, bp, w, bias=None):
         """bias: optional (src, grad_name, rows_key, base, n_out, rows_per_out, row_step) for the row-sum kernel."""
-        ctx = self._fork()
-        if ctx is None:
-            op.backward_weight(dy, x, self.grad_view(name), bp, w["slab"])
-            if bias is not None:
-                self._bias_grad(bias, bp)
+        slab = w["slabs"][id(op)]
+        if not MULTI_REDUCE:
+            # default: GEMM + reduction + bias sums all on the side stream, overlapped with the data-gradient chain
+            ctx = self._fork() or contextlib.nullcontext()
+            with ctx:
+                op.backward_weight(dy, x, self.grad_view(name), bp, slab)
+                if bias is not None:
+                    src, gname, key, base, n_out, rows_per, step = bias
+                    ops.row_sums(src, self.grad_view(gname), self._rows(key, base, len(base)), n_out, rows_per, step, bp)
             return
+        self._pending_red.append((op, slab, self.grad_view(name)))
+        if bias is not None:
+            src, gname, key, base, n_out, rows_per, step = bias
+            self._pending_rs.append((src, self.grad_view(gname), self._rows(key, base, len(base)), n_out, rows_per, step))
+        ctx = self._fork() or contextlib.nullcontext()
         with ctx:
-            op.backward_weight(dy, x, self.grad_view(name), bp, w["slab%d" % self._turn])
-            if bias is not None:
-                self._bias_grad(bias, bp)
-
-    def _bias_grad(self, b, bp):
-        src, gname, key, base, n_out, rows_per, step = b
-        ops.row_sums(src, self.grad_view(gname), self._rows(key, base, len(base)), n_out, rows_per, step, bp)
+            op.wgrad_gemm(dy, x, bp, slab)
 
     def _backward(self, w, phase2, eps, B, bp):
         hp, p, L = self.hp, self.p, self.p.L
+        self._pending_red, self._pending_rs = [], []
         enc_w, enc_b, dconv = self.names()
         # ---------------- decoder ----------------
         for i in range(L - 1, -1, -1):
@@ -472,6 +490,10 @@ class VaeEngine:
             if i > 0:
                 conv.backward_data(w["dY%d" % i], w["dA%d" % (i - 1)], bp)
         self._join()
+        if MULTI_REDUCE:
+            if self._multired is None:
+                self._multired = ops.MultiReduce(self.device)
+            self._multired.run(self._pending_red, self._pending_rs, bp)
 
     # ------------------------------------------------------------------------------------------
     # inference pieces (test()/gen_seq()/_decode)

@@ -288,8 +288,36 @@ class MaskedGemm:
         return self.n_split(bp) * self.n_tiles * self.wg.mt * 16 * 64
 
     def backward_weight(self, dy, x, dw, bp, slab, accumulate=False):
+        self.wgrad_gemm(dy, x, bp, slab)
+        r = self.reduce_desc(slab, dw, bp, accumulate)
+        _lib.check(_lib.load().hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce")
+
+    def reduce_desc(self, slab, dw, bp, accumulate=False):
+        """Descriptor of the slab -> dense-gradient reduction (for hmvae_wgrad_reduce[_multi])."""
+        n_rows, n_chan, kt = self.w_shape
+        ns = self.n_split(bp)
         if self.wg_transposed:
-            return self._backward_weight_t(dy, x, dw, bp, slab, accumulate)
+            b = self.bwd
+            g = b.g
+            return _lib.WreduceDesc(_lib.ptr(slab), _lib.ptr(dw), _lib.ptr(self.tile_g_t), _lib.ptr(self.tile_col0_t),
+                                    _lib.ptr(self.g_ncols_t), _lib.ptr(b.g_choff), _lib.ptr(b.chan_id), _lib.ptr(b.row_id),
+                                    _lib.ptr(b.g_nc4), _lib.ptr(b.g_okoff), _lib.ptr(b.pair_ok), self.n_tiles_t, g.mt, g.kt,
+                                    ns, kt, n_chan * kt, 1 if accumulate else 0)
+        g, tb = self.wg, self.wg_tabs
+        return _lib.WreduceDesc(_lib.ptr(slab), _lib.ptr(dw), _lib.ptr(self.tile_g), _lib.ptr(self.tile_col0),
+                                _lib.ptr(self.g_ncols), _lib.ptr(tb["g_choff"]), _lib.ptr(tb["chan_id"]),
+                                _lib.ptr(tb["row_id"]), _lib.ptr(tb["g_nc4"]), _lib.ptr(tb["g_okoff"]),
+                                _lib.ptr(tb["pair_ok"]), self.n_tiles, g.mt, g.kt, ns, n_chan * kt, kt,
+                                1 if accumulate else 0)
+
+    def reduce_elems(self):
+        if self.wg_transposed:
+            return self.n_tiles_t * self.bwd.g.mt * 16 * 64
+        return self.n_tiles * self.wg.mt * 16 * 64
+
+    def wgrad_gemm(self, dy, x, bp, slab):
+        if self.wg_transposed:
+            return self._wgrad_gemm_t(dy, x, bp, slab)
         lib = _lib.load()
         g = self.wg
         tb = self.wg_tabs
@@ -301,16 +329,9 @@ class MaskedGemm:
                            _lib.ptr(self.dz_rows), self.n_tiles, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"],
                            ge["stride"], ge["pad"], ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 0)
         _lib.check(lib.hmvae_wgrad_gemm(C.byref(d), _lib.stream()), "wgrad_gemm")
-        n_rows, n_chan, kt = self.w_shape
-        r = _lib.WreduceDesc(_lib.ptr(slab), _lib.ptr(dw), _lib.ptr(self.tile_g), _lib.ptr(self.tile_col0),
-                             _lib.ptr(self.g_ncols), _lib.ptr(tb["g_choff"]), _lib.ptr(tb["chan_id"]),
-                             _lib.ptr(tb["row_id"]), _lib.ptr(tb["g_nc4"]), _lib.ptr(tb["g_okoff"]),
-                             _lib.ptr(tb["pair_ok"]), self.n_tiles, g.mt, g.kt, ns, n_chan * kt, kt,
-                             1 if accumulate else 0)
-        _lib.check(lib.hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce")
 
 
-def _mg_backward_weight_t(self, dy, x, dw, bp, slab, accumulate=False):
+def _mg_wgrad_gemm_t(self, dy, x, bp, slab):
     """Transposed orientation (see hmvae_wgrad_desc.transposed): tiles come from the backward-data grouping."""
     lib = _lib.load()
     b = self.bwd
@@ -323,15 +344,10 @@ def _mg_backward_weight_t(self, dy, x, dw, bp, slab, accumulate=False):
                        self.n_tiles_t, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"], ge["stride"], ge["pad"],
                        ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 1)
     _lib.check(lib.hmvae_wgrad_gemm(C.byref(d), _lib.stream()), "wgrad_gemm(T)")
-    n_rows, n_chan, kt = self.w_shape
-    r = _lib.WreduceDesc(_lib.ptr(slab), _lib.ptr(dw), _lib.ptr(self.tile_g_t), _lib.ptr(self.tile_col0_t),
-                         _lib.ptr(self.g_ncols_t), _lib.ptr(b.g_choff), _lib.ptr(b.chan_id), _lib.ptr(b.row_id),
-                         _lib.ptr(b.g_nc4), _lib.ptr(b.g_okoff), _lib.ptr(b.pair_ok), self.n_tiles_t, g.mt, g.kt, ns, kt,
-                         n_chan * kt, 1 if accumulate else 0)
-    _lib.check(lib.hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce(T)")
 
 
-MaskedGemm._backward_weight_t = _mg_backward_weight_t
+MaskedGemm._wgrad_gemm_t = _mg_wgrad_gemm_t
+
 
 
 def conv_gemm(device, neigh, cin, cout, kt, stride, pad, pad_mode, t_in, need_dx=True, out_chan_map=None):
@@ -535,3 +551,39 @@ class MultiPack:
             self.n_ops, self.total, self.kmax, self.key = len(sides_and_weights), start, kmax, key
         _lib.check(_lib.load().hmvae_pack_weights_multi(self.table.data_ptr(), self.n_ops, self.total, self.kmax,
                                                         _lib.stream()), "pack_weights_multi")
+
+
+class MultiReduce:
+    """All slab->dense weight-gradient reductions and all bias row-sums of a step as two launches."""
+
+    def __init__(self, device):
+        self.device = device
+        self.key = None
+
+    def run(self, reduces, rowsums, bp):
+        """reduces: [(op, slab, dw)], rowsums: [(src, dst, rows_tensor, n_out, rows_per_out, row_step)]"""
+        key = (int(bp),) + tuple((id(o), s.data_ptr(), d.data_ptr()) for o, s, d in reduces) + \
+            tuple((s.data_ptr(), d.data_ptr()) for s, d, *_ in rowsums)
+        if key != self.key:
+            descs = (_lib.WreduceDesc * len(reduces))()
+            starts = [0]
+            for i, (op, slab, dw) in enumerate(reduces):
+                descs[i] = op.reduce_desc(slab, dw, bp)
+                nb = min(2048, max(1, (op.reduce_elems() + 255) // 256))
+                starts.append(starts[-1] + nb)
+            self.rd = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device)
+            self.rs = torch.tensor(starts, dtype=torch.int32, device=self.device)
+            self.n_red, self.red_blocks = len(reduces), starts[-1]
+            arr = (_lib.RowsumOp * max(1, len(rowsums)))()
+            st = 0
+            for i, (src, dst, rows, n_out, rpo, step) in enumerate(rowsums):
+                arr[i] = _lib.RowsumOp(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(rows), n_out, rpo, step, int(bp), 0, st)
+                st += n_out
+            self.ro = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            self.n_rs, self.rs_blocks, self.key = len(rowsums), st, key
+        lib = _lib.load()
+        _lib.check(lib.hmvae_wgrad_reduce_multi(self.rd.data_ptr(), self.rs.data_ptr(), self.n_red, self.red_blocks,
+                                                _lib.stream()), "wgrad_reduce_multi")
+        if self.n_rs:
+            _lib.check(lib.hmvae_row_sums_multi(self.ro.data_ptr(), self.n_rs, self.rs_blocks, _lib.stream()),
+                       "row_sums_multi")

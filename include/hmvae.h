@@ -150,6 +150,11 @@ typedef struct {
 
 int hmvae_wgrad_reduce(const hmvae_wreduce_desc* desc, hmvae_stream_t stream);
 
+/* Several reductions in one launch: descs_dev[i] as above, block_start_dev[i] = first workgroup of reduction i
+ * (exclusive prefix sum, n_ops+1 entries; give each one ~ceil(tiles*mt*16*64/256) workgroups, capped as you like). */
+int hmvae_wgrad_reduce_multi(const hmvae_wreduce_desc* descs_dev, const int32_t* block_start_dev, int32_t n_ops,
+                             int32_t total_blocks, hmvae_stream_t stream);
+
 /* packed[g][c4][tap][mt][kk*16+m] = dense[row_id*row_stride + chan_id*chan_stride + tap*tap_stride]
  * (0 for -1 ids and for (row, channel) pairs outside the mask: this is skeleton.py:96 `weight * mask`) */
 int hmvae_pack_weights(const float* dense, float* packed, const int32_t* g_nc4, const int32_t* g_woff,
@@ -203,6 +208,16 @@ int hmvae_leaky_bwd(const float* dout, const float* out, float* dy, int64_t bloc
  * columns are zero by construction) */
 int hmvae_row_sums(const float* src, float* dst, const int32_t* rows, int32_t n_out, int32_t rows_per_out,
                    int32_t row_step, int32_t n_cols, int32_t accumulate, hmvae_stream_t stream);
+/* Several row-sum jobs (bias gradients) in one launch; one workgroup per output element. */
+typedef struct {
+    const float* src;
+    float* dst;
+    const int32_t* rows;
+    int32_t n_out, rows_per_out, row_step, n_cols, accumulate, block_start;
+} hmvae_rowsum_op;
+
+int hmvae_row_sums_multi(const hmvae_rowsum_op* ops_dev, int32_t n_ops, int32_t total_blocks, hmvae_stream_t stream);
+
 /* AoS (B, T, C) <-> SoA (C, T, Bp) */
 int hmvae_aos_to_soa(const float* aos, float* soa, int32_t B, int32_t T, int32_t C, int32_t bp, hmvae_stream_t stream);
 int hmvae_soa_to_aos(const float* soa, float* aos, int32_t B, int32_t T, int32_t C, int32_t bp, hmvae_stream_t stream);
