@@ -79,12 +79,25 @@ def instrument_gemms(engine, timer, bp):
     all_ops = engine.enc_conv + engine.dec_conv + engine.enc_lin + list(engine.dec_lin.values())
     for op in all_ops:
         useful_f = 2.0 * op.useful_macs_per_col
-        restore.append((op.fwd, "run", timer.wrap(op.fwd, "run", "gather_gemm_kernel", lambda *a, _f=useful_f, **k: _f * a[2] if len(a) > 2 else 0.0)))
+        restore.append((op.fwd, "run", timer.wrap(op.fwd, "run", "gather_gemm2_kernel", lambda *a, _f=useful_f, **k: _f * a[2] if len(a) > 2 else 0.0)))
         if op.bwd is not None:
-            restore.append((op.bwd, "run", timer.wrap(op.bwd, "run", "gather_gemm_kernel", lambda *a, _f=useful_f, **k: _f * a[2] if len(a) > 2 else 0.0)))
+            restore.append((op.bwd, "run", timer.wrap(op.bwd, "run", "gather_gemm2_kernel", lambda *a, _f=useful_f, **k: _f * a[2] if len(a) > 2 else 0.0)))
         restore.append((op, "backward_weight", timer.wrap(op, "backward_weight", "wgrad_kernel(+reduce)",
                                                            lambda *a, _f=useful_f, **k: _f * a[3])))
     return restore
+
+
+def load_traffic(kernel, batch, phase):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/profile_round.sh + tools/pmc_traffic.py:
+    separate FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 x2 fetch correction).  None when the profile
+    on disk is for another workload."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files or batch != 256 or phase != 2:
+        return None, None
+    d = json.load(open(files[-1]))
+    k = d["kernels"].get(kernel)
+    return (k["traffic_bytes_per_launch"], os.path.basename(files[-1])) if k else (None, None)
 
 
 def fk_microbench(device, iters=20):
@@ -250,8 +263,10 @@ def main():
         fam = max(agg.items(), key=lambda kv: kv[1][0])
         label, (ms, fl, cnt) = fam
         tfl = fl / (ms * 1e-3) / 1e12
+        traffic, tsrc = load_traffic(label.split("(")[0], B, args.phase)
         out["roofline"] = {"kernel": label, "bound": "mfma", "achieved": tfl, "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": tfl / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "unit": "TFLOP/s", "frac": tfl / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                           "traffic_unit": "HBM-side bytes per launch (PMC)", "traffic_source": tsrc,
                            "launches_per_step": cnt // n_inst, "avg_launch_us": ms / cnt * 1e3,
                            "flops_per_step_effective": fl / n_inst,
                            "all_kernels": {k: {"ms_per_step": v[0] / n_inst, "TFLOP/s": v[1] / (v[0] * 1e-3) / 1e12}

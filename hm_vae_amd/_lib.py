@@ -36,6 +36,17 @@ class Gemm2Desc(C.Structure):
                 ("dst_ts", _i32), ("flags", _i32), ("slope", _f32), ("debug", _ptr)]
 
 
+class Conv3Desc(C.Structure):
+    _fields_ = [("src", _ptr), ("dst", _ptr), ("wp", _ptr), ("bias", _ptr), ("bias_idx", _ptr),
+                ("chan_rows", _ptr), ("dst_rows", _ptr),
+                ("wave_tab", _ptr), ("win_rows", _ptr), ("items", _ptr), ("segs", _ptr), ("worker_seg", _ptr),
+                ("fixups", _ptr),
+                ("scratch", _ptr), ("n_groups", _i32), ("kt", _i32), ("bp", _i32), ("n_chunks", _i32), ("ts", _i32),
+                ("win", _i32), ("max_nc4", _i32), ("max_items", _i32), ("un", _i32), ("n_workers", _i32),
+                ("n_fixups", _i32), ("lds_floor", _i32), ("src_ts", _i32), ("dst_ts", _i32), ("flags", _i32),
+                ("slope", _f32)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [("dz", _ptr), ("x", _ptr), ("slab", _ptr), ("tile_g", _ptr), ("tile_col0", _ptr), ("g_ncols", _ptr),
                 ("g_choff", _ptr), ("chan_rows", _ptr), ("dz_rows", _ptr), ("n_tiles", _i32), ("n_groups", _i32),
@@ -74,6 +85,7 @@ _SIGS = {
     "hmvae_error_string": ([_i32], C.c_char_p),
     "hmvae_gather_gemm": ([C.POINTER(GemmDesc), _ptr], _i32),
     "hmvae_gather_gemm_v2": ([C.POINTER(Gemm2Desc), _ptr], _i32),
+    "hmvae_gather_gemm_v3": ([C.POINTER(Conv3Desc), _ptr], _i32),
     "hmvae_wgrad_gemm": ([C.POINTER(WgradDesc), _ptr], _i32),
     "hmvae_wgrad_reduce": ([C.POINTER(WreduceDesc), _ptr], _i32),
     "hmvae_pack_weights": ([_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),

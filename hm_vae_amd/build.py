@@ -8,7 +8,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libhmvae_hip.so")
-SOURCES = ["gemm_kernels.hip", "gemm_v2.hip", "elementwise_kernels.hip", "fk_kernels.hip"]
+SOURCES = ["gemm_kernels.hip", "gemm_v2.hip", "gemm_v3.hip", "elementwise_kernels.hip", "fk_kernels.hip"]
 
 
 def _newer(target, deps):
@@ -21,6 +21,8 @@ def _newer(target, deps):
 def build(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
     extra = ["-DHMVAE_STAMP"] if os.environ.get("HMVAE_STAMP") else []      # diagnostic build (tools/stamp_gemm.py)
+    if os.environ.get("HMVAE_ABLATE"):                                        # diagnostic build (tools/ablate_v3.py)
+        extra.append("-DHMVAE_ABLATE")
     if extra:
         force = True
     srcs = [os.path.join(CSRC, s) for s in SOURCES]

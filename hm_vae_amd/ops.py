@@ -18,6 +18,32 @@ import os as _os
 
 USE_V2 = _os.environ.get("HMVAE_GEMM", "v2") != "v1"
 AUTOTUNE = _os.environ.get("HMVAE_AUTOTUNE", "1") != "0"
+# optional JSON file that persists the autotuner's choices between processes (profiling runs reuse it so the trace
+# holds only the launches of the timed steps)
+TUNE_CACHE = _os.environ.get("HMVAE_TUNE_CACHE")
+_tune_cache = None
+
+
+def _tune_cache_get(key):
+    global _tune_cache
+    if TUNE_CACHE is None:
+        return None
+    if _tune_cache is None:
+        import json
+        try:
+            _tune_cache = json.load(open(TUNE_CACHE))
+        except (OSError, ValueError):
+            _tune_cache = {}
+    return _tune_cache.get(key)
+
+
+def _tune_cache_put(key, val):
+    if TUNE_CACHE is None:
+        return
+    import json
+    _tune_cache[key] = list(val)
+    with open(TUNE_CACHE, "w") as f:
+        json.dump(_tune_cache, f)
 XCD_MODE = None if _os.environ.get("HMVAE_XCD") is None else int(_os.environ["HMVAE_XCD"])
 DEBUG_BUF = None          # diagnostic builds only (tools/stamp_gemm.py)
 
@@ -59,6 +85,8 @@ class _Side:
         p_off, p_len, flat = P.flatten_pairs(pairs)
         self.pairs_host = pairs
         self._items = {}
+        self._wplans = {}
+        self._sched = {}
         self._tuned = {}
         self.tune = None                      # (cw, ksplit) override for experiments
         self.n_pos = len(pairs)
@@ -91,6 +119,71 @@ class _Side:
                                 int(pb_len.max()))
         return self._items[np_]
 
+    def window_plan(self, chunk, ts):
+        """Device tables of the v3 window kernel for (positions per workgroup, waves per position), or None."""
+        key = (chunk, ts)
+        if key not in self._wplans:
+            plan = P.pick_window_un(self.pairs_host, self.g.kt, chunk, ts) if self.g.mt == 1 else None
+            if plan is not None:
+                lds = 2 * (4 * plan["win"] * 256 + (self.g.kt + 1) * 256) + 8192
+                if lds > 150 * 1024 or int(self.g.g_nc4.max()) > 512:
+                    plan = None
+            if plan is not None:
+                for k in ("wave_tab", "items", "win_rows"):
+                    plan[k] = _dev(plan[k], self.device)
+            self._wplans[key] = plan
+        return self._wplans[key]
+
+    def stream_schedule(self, bp, chunk, ts):
+        """Persistent-launch schedule of the v3 kernel for this batch size: equal shares of the layer's K steps for
+        (CUs x resident workgroups) workers (planner.build_stream_schedule), as device tables + the scratch tiles."""
+        key = (int(bp), chunk, ts)
+        if key in self._sched:
+            return self._sched[key]
+        plan = self.window_plan(chunk, ts)
+        g = self.g
+        n_ct = int(bp) // 64
+        n_chunks = plan["n_chunks"]
+        if self.xcd_mode() == 0:        # group-major: an XCD's L2 sees the weights of a few groups
+            order = [(gi, pc, ct) for gi in range(g.n_groups) for pc in range(n_chunks) for ct in range(n_ct)]
+        else:                           # position-major, group fastest: an XCD sees a slice of the activations
+            order = [(gi, pc, ct) for pc in range(n_chunks) for ct in range(n_ct) for gi in range(g.n_groups)]
+        chunk_cost = plan["chunk_cost"]
+        steps = [int(g.g_nc4[gi]) for gi, _, _ in order]
+        cost = [int(chunk_cost[pc]) for _, pc, _ in order]
+        lds = 8192 + 2 * (4 * plan["win"] * 256 + (g.kt + 1) * 256)
+        per_cu = 2 if lds <= 80 * 1024 else 1
+        n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 256
+        n_workers = max(8, (n_cu * per_cu) // 8 * 8)
+        segs, wseg, fix, n_parts = P.build_stream_schedule(steps, cost, n_workers)
+        seg_t = np.zeros((max(len(segs), 1), 8), dtype=np.int32)
+        for i, (u, k0, k1, part) in enumerate(segs):
+            gi = order[u][0]
+            seg_t[i] = (*order[u], k0, k1, part, int(g.g_choff[gi]), int(g.g_woff[gi]))
+        fix_t = np.zeros((max(len(fix), 1), 8), dtype=np.int32)
+        for i, (u, p0, npart) in enumerate(fix):
+            fix_t[i, :5] = (*order[u], p0, npart)
+        sched = dict(segs=_dev(seg_t.reshape(-1), self.device), worker_seg=_dev(wseg.astype(np.int32).reshape(-1), self.device),
+                     fixups=_dev(fix_t.reshape(-1), self.device), n_fixups=len(fix), n_workers=n_workers,
+                     scratch=torch.empty(max(n_parts, 1) * (8 // ts) * 1024, dtype=torch.float32, device=self.device),
+                     lds_floor=(54 * 1024 if per_cu == 2 else 0))
+        self._sched[key] = sched
+        return sched
+
+    def run_v3(self, src, dst, bp, bias, flags, slope, chunk, ts):
+        plan = self.window_plan(chunk, ts)
+        if plan is None:
+            raise _lib.HmvaeError("window plan (%d, %d) unavailable for this relation" % (chunk, ts))
+        g = self.g
+        sc = self.stream_schedule(bp, chunk, ts)
+        d = _lib.Conv3Desc(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(self.wp), _lib.ptr(bias), _lib.ptr(self.bias_idx),
+                           _lib.ptr(self.chan_rows), _lib.ptr(self.dst_rows), _lib.ptr(plan["wave_tab"]),
+                           _lib.ptr(plan["win_rows"]), _lib.ptr(plan["items"]), _lib.ptr(sc["segs"]), _lib.ptr(sc["worker_seg"]),
+                           _lib.ptr(sc["fixups"]), _lib.ptr(sc["scratch"]), g.n_groups, g.kt, int(bp), plan["n_chunks"],
+                           plan["ts"], plan["win"], int(g.g_nc4.max()), plan["max_items"], plan["un"], sc["n_workers"],
+                           sc["n_fixups"], sc["lds_floor"], self.src_ts, self.dst_ts, int(flags), float(slope))
+        _lib.check(_lib.load().hmvae_gather_gemm_v3(C.byref(d), _lib.stream()), "gather_gemm_v3")
+
     def xcd_mode(self):
         """Small packed weights (they fit in every XCD's 4 MB L2 next to the activations): balance the unequal groups
         over the XCDs and give each XCD a slice of the positions.  Big (dense) weights: keep each XCD on its own groups."""
@@ -113,6 +206,12 @@ class _Side:
         if bp in self._tuned or self.tune is not None or not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return
         g = self.g
+        ck = "g%d_w%d_p%d_s%d_d%d_m%d_st%s_b%d" % (g.n_groups, g.packed_size, self.n_pos, self.src_ts, self.dst_ts, g.mt,
+                                                    "x".join(map(str, self.strides)), bp)
+        hit = _tune_cache_get(ck)
+        if hit is not None:
+            self._tuned[bp] = (int(hit[0]), int(hit[1]))
+            return
         scratch = torch.empty_like(dst)
         fl = int(flags) & ~_lib.FLAG_ACCUM
         best = None
@@ -138,6 +237,7 @@ class _Side:
                     best = (t, cw, ks)
         self.tune = None
         self._tuned[bp] = (best[1], best[2])
+        _tune_cache_put(ck, self._tuned[bp])
 
     def run(self, src, dst, bp, bias=None, flags=0, slope=0.2):
         if USE_V2:

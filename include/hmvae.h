@@ -102,6 +102,53 @@ typedef struct {
 int hmvae_gather_gemm_v2(const hmvae_gemm2_desc* desc, hmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Window gather-GEMM (third generation) for the temporal convolutions: SkeletonConv forward and
+ * backward-data (skeleton.py:95-105), 16-row groups only.  Same operands and epilogue as v2.
+ * A UNIT is (row group, chunk of neighbouring output positions, 64 batch columns).  The contiguous
+ * window of source positions [chunk_q0, chunk_q0 + win) a chunk reads is staged in LDS once per
+ * 4-channel K step and shared by the 8 waves of the workgroup; each wave owns one output position
+ * of the chunk (ts == 1) or one of `ts` slices of its items, summed through LDS.
+ *   items       = [n_chunks][8][32] int32, (window row) | (tap << 16); every wave's item count
+ *                 (<= 16) is padded to a multiple of `un` with items whose tap == kt (an all-zero
+ *                 weight fragment)
+ *   wave_tab    = [n_chunks][8][4] int32: {output position or -1, pattern, item count, 0}; waves
+ *                 w*ts .. w*ts+ts-1 share an output position.  pattern 1: the 15 items are (r0+i,
+ *                 tap i); pattern 2: (r0+i, tap 14-i); 0: anything (only with un == 5 may it be != 0)
+ *   win_rows    = [n_chunks][win] int32: source position staged in each window row
+ * The launch is persistent: n_workers workgroups (a multiple of 8), worker w runs the segments
+ * worker_seg[2w] .. +worker_seg[2w+1];  segs[s] = {group, chunk, column tile, k0, k1, part,
+ * g_choff[group], g_woff[group]} is the K-step range [k0, k1) of a unit.  part < 0: the segment covers the whole unit and stores
+ * to dst.  part >= 0: the unit was cut between workers; the raw tile goes to scratch[part] and
+ * fixups[f] = {group, chunk, column tile, first part, n parts, 0, 0, 0} lists the cut units, whose
+ * parts are summed in K order by a second launch.  planner.py builds the schedule so that every
+ * worker issues the same number of MFMAs.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* src;
+    float* dst;
+    const float* wp;         /* packed weights of 16-row groups, as for v2 (hmvae_pack_weights) */
+    const float* bias;
+    const int32_t* bias_idx;
+    const int32_t* chan_rows;
+    const int32_t* dst_rows;
+    const int32_t* wave_tab; /* [n_chunks][8][4] */
+    const int32_t* win_rows; /* [n_chunks][win] */
+    const int32_t* items;    /* [n_chunks][8][32] */
+    const int32_t* segs;     /* [n_segs][8] */
+    const int32_t* worker_seg;/* [n_workers][2] */
+    const int32_t* fixups;   /* [n_fixups][8] */
+    float* scratch;          /* [n_parts][8/ts][16][64] partial tiles of cut units */
+    int32_t n_groups, kt, bp, n_chunks, ts, win, max_nc4, max_items, un;
+    int32_t n_workers, n_fixups;
+    int32_t lds_floor;       /* request at least this much LDS per workgroup (pins the workgroups per CU the schedule
+                                was made for); 0 = only what the kernel needs */
+    int32_t src_ts, dst_ts, flags;
+    float slope;
+} hmvae_conv3_desc;
+
+int hmvae_gather_gemm_v3(const hmvae_conv3_desc* desc, hmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Weight-gradient GEMM (autograd of skeleton.py:95-105 / nn.Linear w.r.t. weight), split over the
  * (position, batch) reduction into `n_split` slabs, then a deterministic reduce into the dense grad.
  * slab[s][tile][mt*16][64] = sum_{t,b in split s} dz[dz_rows[g,r] + t*dz_ts][b] *

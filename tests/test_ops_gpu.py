@@ -121,6 +121,23 @@ def test_skeleton_conv_fwd_bwd(dev, case):
     op.backward_data(gys, dxs, bp, accumulate=True)
     assert rel_err(bct_from_soa(dxs, B, cin, T).numpy(), 2 * x.grad.numpy()) < TOL
 
+    # the window kernel (v3) in every workgroup shape, forward and backward-data, against the same reference
+    n_v3 = 0
+    for chunk, ts in ((8, 1), (4, 2), (2, 4), (1, 8)):
+        if op.fwd.window_plan(chunk, ts) is not None:
+            y3 = torch.full((cout * T_out, bp), float("nan"), device=dev)
+            op.fwd.run_v3(xs, y3, bp, b.detach().to(dev), _lib.FLAG_LEAKY if case["leaky"] else 0, 0.2, chunk, ts)
+            assert rel_err(bct_from_soa(y3, B, cout, T_out).numpy(), y.detach().numpy()) < TOL, (chunk, ts)
+            n_v3 += 1
+        if op.bwd.window_plan(chunk, ts) is not None:
+            dx3 = torch.full((cin * T, bp), float("nan"), device=dev)
+            op.bwd.run_v3(gys, dx3, bp, None, 0, 0.2, chunk, ts)
+            assert rel_err(bct_from_soa(dx3, B, cin, T).numpy(), x.grad.numpy()) < TOL, (chunk, ts)
+            op.bwd.run_v3(gys, dx3, bp, None, _lib.FLAG_ACCUM, 0.2, chunk, ts)
+            assert rel_err(bct_from_soa(dx3, B, cin, T).numpy(), 2 * x.grad.numpy()) < TOL, (chunk, ts)
+            n_v3 += 1
+    assert n_v3 > 0
+
     dw = torch.zeros(cout, cin, K, device=dev)
     slab = torch.empty(op.slab_floats(bp), device=dev)
     op.backward_weight(gys, xs, dw, bp, slab)

@@ -25,6 +25,9 @@ else:
     out = torch.zeros(nrows, bp, device=dev)
     if np_ is not None: side.tune = (np_, ks)
     fn = (lambda: side.run_v1(src, out, bp)) if ver == "v1" else (lambda: side.run_v2(src, out, bp))
+    if ver == "v3":       # np ks are (chunk, ts) here
+        side.tune = None
+        fn = lambda: side.run_v3(src, out, bp, None, 0, 0.2, np_, ks)
 for _ in range(reps): fn()
 torch.cuda.synchronize()
 print("done", layer, dirn, ver, np_, ks)
