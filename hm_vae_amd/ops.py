@@ -18,6 +18,7 @@ import os as _os
 
 USE_V2 = _os.environ.get("HMVAE_GEMM", "v2") != "v1"
 AUTOTUNE = _os.environ.get("HMVAE_AUTOTUNE", "1") != "0"
+USE_V3 = _os.environ.get("HMVAE_V3", "1") != "0"        # let the autotuner consider the v3 window kernel
 # optional JSON file that persists the autotuner's choices between processes (profiling runs reuse it so the trace
 # holds only the launches of the timed steps)
 TUNE_CACHE = _os.environ.get("HMVAE_TUNE_CACHE")
@@ -88,6 +89,7 @@ class _Side:
         self._wplans = {}
         self._sched = {}
         self._tuned = {}
+        self._tuned_v2 = {}
         self.tune = None                      # (cw, ksplit) override for experiments
         self.n_pos = len(pairs)
         self.p_off, self.p_len, self.pairs = _dev(p_off, device), _dev(p_len, device), _dev(flat, device)
@@ -192,17 +194,32 @@ class _Side:
         return 1 if self.g.packed_size * 4 <= (8 << 20) else 0
 
     def choose(self, bp):
+        """(cw, ksplit) of the v2 kernel for this batch size."""
         if self.tune is not None:
             return self.tune
-        if bp in self._tuned:
-            return self._tuned[bp]
+        if bp in self._tuned_v2:
+            return self._tuned_v2[bp]
         g = self.g
         return P.pick_np_ksplit(g.mt, g.n_groups, self.n_pos, bp // 64, float(g.g_nc4.mean()))
 
+    def _time(self, fn):
+        for _ in range(2):
+            fn()
+        evs = []
+        for _ in range(4):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        return sorted(x.elapsed_time(y) for x, y in evs)[1]
+
     def autotune(self, src, dst, bp, bias, flags, slope):
-        """Measure, don't guess: time the (column units per wave, K split) candidates once per batch size on the real
-        operands (HIP events, scratch destination) and keep the fastest.  Runs during warm-up, never inside a graph
-        capture.  HMVAE_AUTOTUNE=0 falls back to the static heuristic."""
+        """Measure, don't guess: time the candidates once per batch size on the real operands (HIP events, scratch
+        destination) and keep the fastest: the v2 kernel's (column units per wave, K split), and -- for the temporal
+        convolutions -- the v3 window kernel's (positions per workgroup, waves per position).  Runs during warm-up,
+        never inside a graph capture.  HMVAE_AUTOTUNE=0 falls back to the static v2 heuristic."""
         if bp in self._tuned or self.tune is not None or not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return
         g = self.g
@@ -210,7 +227,8 @@ class _Side:
                                                     "x".join(map(str, self.strides)), bp)
         hit = _tune_cache_get(ck)
         if hit is not None:
-            self._tuned[bp] = (int(hit[0]), int(hit[1]))
+            self._tuned[bp] = tuple(hit)
+            self._tuned_v2[bp] = tuple(hit[3:5]) if hit[0] == "v3" else tuple(hit)
             return
         scratch = torch.empty_like(dst)
         fl = int(flags) & ~_lib.FLAG_ACCUM
@@ -222,28 +240,33 @@ class _Side:
                 if ks > 1 and float(g.g_nc4.mean()) / ks < 1.0:
                     continue
                 self.tune = (cw, ks)
-                for _ in range(2):
-                    self.run_v2(src, scratch, bp, bias, fl, slope)
-                evs = []
-                for _ in range(4):
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                    self.run_v2(src, scratch, bp, bias, fl, slope)
-                    b.record()
-                    evs.append((a, b))
-                torch.cuda.synchronize()
-                t = sorted(x.elapsed_time(y) for x, y in evs)[1]
+                t = self._time(lambda: self.run_v2(src, scratch, bp, bias, fl, slope))
                 if best is None or t < best[0]:
                     best = (t, cw, ks)
         self.tune = None
-        self._tuned[bp] = (best[1], best[2])
-        _tune_cache_put(ck, self._tuned[bp])
+        self._tuned_v2[bp] = (best[1], best[2])
+        pick = (best[1], best[2])
+        if USE_V3 and self.n_pos >= 4 and g.kt > 1:
+            for chunk, ts in ((8, 1), (4, 2)):
+                if self.window_plan(chunk, ts) is None:
+                    continue
+                t = self._time(lambda: self.run_v3(src, scratch, bp, bias, fl, slope, chunk, ts))
+                if t < 0.97 * best[0]:
+                    best = (t, best[1], best[2])
+                    pick = ("v3", chunk, ts, self._tuned_v2[bp][0], self._tuned_v2[bp][1])
+            for key in [k for k in self._sched if k[0] == int(bp) and (pick[0] != "v3" or k[1:] != pick[1:3])]:
+                del self._sched[key]            # scratch tiles of the candidates that lost
+        self._tuned[bp] = pick
+        _tune_cache_put(ck, pick)
 
     def run(self, src, dst, bp, bias=None, flags=0, slope=0.2):
-        if USE_V2:
-            self.autotune(src, dst, bp, bias, flags, slope)
-            return self.run_v2(src, dst, bp, bias, flags, slope)
-        return self.run_v1(src, dst, bp, bias, flags, slope)
+        if not USE_V2:
+            return self.run_v1(src, dst, bp, bias, flags, slope)
+        self.autotune(src, dst, bp, bias, flags, slope)
+        pick = self._tuned.get(bp)
+        if pick is not None and pick[0] == "v3" and self.tune is None:
+            return self.run_v3(src, dst, bp, bias, flags, slope, pick[1], pick[2])
+        return self.run_v2(src, dst, bp, bias, flags, slope)
 
     def run_v2(self, src, dst, bp, bias=None, flags=0, slope=0.2):
         lib = _lib.load()

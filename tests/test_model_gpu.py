@@ -126,8 +126,10 @@ def test_two_trainer_steps_vs_reference(dev, tag):
         idx = g["upd|" + name + "|idx"]
         delta = v[idx].astype(np.float64) - seeded[name].reshape(-1).numpy()[idx].astype(np.float64)
         ref = g["upd|" + name + "|delta"]
-        # the first Adam steps move every touched weight by ~lr; 1% of lr is far below one step
-        assert np.abs(delta - ref).max() < 1e-2 * cfg["lr"], name
+        # the first Adam steps move every touched weight by ~lr; 2% of lr is far below one step.  (Not tighter: the
+        # encoder's first bias gradients are ~4e-8, a cancelling sum over (t, batch) of terms 1000x larger and only a
+        # few times Adam's eps, so d(update)/d(grad) is ~4e6*lr there and fp32 summation order alone moves it by 1%.)
+        assert np.abs(delta - ref).max() < 2e-2 * cfg["lr"], name
     assert abs(tr.gen_opt.param_groups[0]["lr"] - meta["lr_after_2"]) < 1e-12
     # attributes the reference's write_loss reflects on
     from hm_vae_amd.utils_common import loss_members

@@ -7,6 +7,7 @@ import torch.nn.functional as F
 
 from oracle import hmvae_oracle as O
 from hm_vae_amd import ops, planner, topology
+from hm_vae_amd import planner as P
 from emu import emu_pack, emu_gather, emu_wgrad
 from helpers import rel_err
 
@@ -160,3 +161,68 @@ def test_items_expand_to_pairs(np_, geom):
     for mt in (1, 2, 3, 4):
         np2, ks = planner.pick_np_ksplit(mt, 7, t_out, 4, 20.0)
         assert np2 * mt <= 4 and ks in (1, 2, 4) and np2 <= max(1, t_out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# window plans + stream-K schedule of the v3 gather-GEMM
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("t_in,t_out,stride", [(64, 64, 1), (8, 8, 1), (64, 32, 2), (8, 4, 2), (16, 16, 1)])
+@pytest.mark.parametrize("chunk,ts", [(8, 1), (4, 2), (2, 4), (1, 8)])
+def test_window_plan_expands_to_pairs(t_in, t_out, stride, chunk, ts):
+    """Every wave's (window row, tap) items, mapped through win_rows, are exactly the (q, tap) pairs of its position."""
+    kt = 15
+    for pairs in (P.conv_pairs_fwd(t_in, t_out, kt, stride, 7, "reflect"), P.conv_pairs_bwd(t_in, t_out, kt, stride, 7, "reflect")):
+        plan = P.pick_window_un(pairs, kt, chunk, ts)
+        if plan is None:            # relation outside the kernel's limits (items per wave): v2 serves it
+            continue
+        win, un = plan["win"], plan["un"]
+        wt = plan["wave_tab"].reshape(-1, 8, 4)
+        items = plan["items"].reshape(-1, 8, 32)
+        rows = plan["win_rows"].reshape(-1, win)
+        assert 4 <= win <= 32 and rows.min() >= 0 and rows.max() < max(q for l in pairs for q, _ in l) + 1
+        got = [[] for _ in pairs]
+        for c in range(wt.shape[0]):
+            for w in range(8):
+                p, pat, n, _ = wt[c, w]
+                assert n % un == 0 and n <= 20
+                lst = [(int(v) & 0xffff, int(v) >> 16) for v in items[c, w, :n]]
+                real = [(r, t) for r, t in lst if t != kt]
+                assert all(t == kt for _, t in lst[len(real):])          # padding (zero fragment) only at the end
+                if pat == 1:
+                    assert real == [(real[0][0] + i, i) for i in range(kt)]
+                if pat == 2:
+                    assert real == [(real[0][0] + i, kt - 1 - i) for i in range(kt)]
+                if p >= 0:
+                    got[p].extend((int(rows[c, r]), t) for r, t in real)
+                else:
+                    assert not real
+        for p, lst in enumerate(pairs):
+            assert sorted(got[p]) == sorted(lst), p
+
+
+def test_stream_schedule_covers_and_balances():
+    rng = np.random.default_rng(0)
+    for n_workers in (8, 256, 512):
+        nc4 = rng.integers(5, 170, size=13)
+        steps = [int(n) for n in nc4 for _ in range(32)]
+        cost = [int(rng.choice([15, 15, 15, 18])) for _ in steps]
+        segs, wseg, fix, n_parts = P.build_stream_schedule(steps, cost, n_workers)
+        cov = np.zeros(len(steps), dtype=np.int64)
+        prev = {}
+        for u, k0, k1, part in segs:
+            assert 0 <= k0 < k1 <= steps[u]
+            assert prev.get(u, 0) == k0            # the parts of a unit are consecutive K ranges, in order
+            prev[u] = k1
+            cov[u] += k1 - k0
+        assert (cov == np.asarray(steps)).all()
+        assert wseg[:, 1].sum() == len(segs) and (wseg[1:, 0] == wseg[:-1, 0] + wseg[:-1, 1]).all()
+        load = np.array([sum((segs[i][2] - segs[i][1]) * cost[segs[i][0]] for i in range(a, a + n)) for a, n in wseg])
+        assert load.max() <= 1.15 * load.mean() + 3 * 18
+        # cut units: every part slot used exactly once, in K order
+        parts = sorted(int(p) for _, _, _, p in segs if p >= 0)
+        assert parts == list(range(n_parts))
+        for u, p0, n in fix:
+            mine = [(k0, p) for uu, k0, _, p in segs if uu == u]
+            assert [p for _, p in sorted(mine)] == list(range(p0, p0 + n)) and n >= 2
+        whole = [u for u, _, _, p in segs if p < 0]
+        assert len(set(whole)) == len(whole)
