@@ -541,47 +541,108 @@ extern "C" int hmvae_pack_weights(const float* dense, float* packed, const int32
 
 
 // ---- every pack of the model in one launch (23 launches of 4-15 us each were mostly launch floor) ----
+// One workgroup packs PACK_CB consecutive 4-channel steps of one group: with 16-row groups that is 256 (row, channel)
+// pairs, one per thread, and a quarter of the workgroups (their life is a chain of dependent table reads, so fewer and
+// fuller ones finish sooner).
+constexpr int PACK_CB = 4;
 __global__ __launch_bounds__(256) void pack_multi_kernel(const hmvae_pack_op* __restrict__ ops, int n_ops) {
-    extern __shared__ float img[];
+    extern __shared__ float img[];                    // [PACK_CB][kt][mt][64]
     int oi = 0;
     for (int i = 1; i < n_ops; ++i)
         if ((int)blockIdx.x >= ops[i].block_start) oi = i;          // uniform scan over <= a few dozen entries
     const hmvae_pack_op o = ops[oi];
     const int local = blockIdx.x - o.block_start;
-    const int g = local / o.max_nc4;
-    const int c4 = local - g * o.max_nc4;
+    const int cblocks = (o.max_nc4 + PACK_CB - 1) / PACK_CB;
+    const int gb = local / cblocks;                                 // group (folded op: group of the unfolded matrix)
+    const int c40 = (local - gb * cblocks) * PACK_CB;
+    const int fmod = o.fold_taps ? o.fold_mod : 1;
+    const int g = gb * fmod;                                        // folded: groups g .. g+fmod-1 are (rows, a = 0..fmod-1)
     const int nc4 = o.g_nc4[g];
-    if (c4 >= nc4) return;
+    if (c40 >= nc4) return;
+    const int ncb = nc4 - c40 < PACK_CB ? nc4 - c40 : PACK_CB;     // steps of this block
     const int mt = o.mt, kt = o.kt;
     const int rows = mt * 16;
+    const int ppc = rows * 4;                                       // pairs per step
+    const int step_floats = kt * mt * 64;
     const bool chan_inner = o.chan_stride < o.row_stride;
-    const int ab = threadIdx.x;
-    if (ab < rows * 4) {
-        int r, kk;
+    const int tid = threadIdx.x;
+    auto pair_rk = [&](int pair, int& r, int& kk) {
         if (chan_inner) {
-            kk = ab & 3;
-            r = ab >> 2;
+            kk = pair & 3;
+            r = pair >> 2;
         } else {
-            r = ab % rows;
-            kk = ab / rows;
+            r = pair % rows;
+            kk = pair / rows;
         }
-        const int rid = o.row_id[g * rows + r];
+    };
+    if (o.fold_taps == nullptr) {
+        // one (row, channel) pair at a time per thread, its kt taps read back to back
+        for (int pi = tid; pi < ncb * ppc; pi += 256) {
+            const int st = pi / ppc, pair = pi - st * ppc, c4 = c40 + st;
+            int r, kk;
+            pair_rk(pair, r, kk);
+            const int rid = o.row_id[g * rows + r];
+            const int cid = o.chan_id[o.g_choff[g] + c4 * 4 + kk];
+            const bool ok = rid >= 0 && cid >= 0 && o.pair_ok[o.g_okoff[g] + r * (nc4 * 4) + c4 * 4 + kk];
+            const float* src = o.dense + (ok ? (size_t)rid * o.row_stride + (size_t)cid * o.chan_stride : 0);
+            float* dsti = img + st * step_floats + (r >> 4) * 64 + kk * 16 + (r & 15);
+            for (int tap = 0; tap < kt; ++tap) dsti[tap * mt * 64] = ok ? src[(size_t)tap * o.tap_stride] : 0.f;
+        }
+        __syncthreads();
+        float* out = o.packed + o.g_woff[g] + (size_t)c40 * step_floats;     // the steps of a group are contiguous
+        const int n = ncb * step_floats;
+        for (int i = tid; i < n; i += 256) out[i] = img[i];
+        return;
+    }
+    // Effective weights of a folded convolution (hmvae.h).  The fmod groups (rows, a) of one unfolded group share rows,
+    // channel list and mask: stage the real taps of the block's (row, channel) pairs once (private to the owning
+    // thread), then build and store the fragments of every a from them.
+    const int kr = o.fold_kt;                              // taps of the dense tensor
+    float* stage = img + PACK_CB * step_floats;            // [step][pair][kr]
+    int* ftab = (int*)(stage + PACK_CB * ppc * kr);        // the op's fold table
+    for (int i = tid; i < (o.fold_swap ? kt : o.fold_mod) * o.fold_tsrc * 4; i += 256) ftab[i] = o.fold_taps[i];
+    for (int pi = tid; pi < ncb * ppc; pi += 256) {
+        const int st = pi / ppc, pair = pi - st * ppc, c4 = c40 + st;
+        int r, kk;
+        pair_rk(pair, r, kk);
+        const int rid = o.row_id[g * rows + r];            // = real * fmod + 0
         const int cid = o.chan_id[o.g_choff[g] + c4 * 4 + kk];
         const bool ok = rid >= 0 && cid >= 0 && o.pair_ok[o.g_okoff[g] + r * (nc4 * 4) + c4 * 4 + kk];
-        const float* src = o.dense + (ok ? (size_t)rid * o.row_stride + (size_t)cid * o.chan_stride : 0);
-        float* dsti = img + (r >> 4) * 64 + kk * 16 + (r & 15);
-        for (int tap = 0; tap < kt; ++tap) dsti[tap * mt * 64] = ok ? src[(size_t)tap * o.tap_stride] : 0.f;
+        const float* src = o.dense + (ok ? (size_t)(rid / fmod) * o.row_stride + (size_t)cid * o.chan_stride : 0);
+        float* mine = stage + pi * kr;
+        for (int k = 0; k < kr; ++k) mine[k] = ok ? src[(size_t)k * o.tap_stride] : 0.f;
     }
-    __syncthreads();
-    float* out = o.packed + o.g_woff[g] + (size_t)c4 * kt * mt * 64;
-    const int n = kt * mt * 64;
-    for (int i = threadIdx.x; i < n; i += 256) out[i] = img[i];
+    for (int a = 0; a < fmod; ++a) {
+        __syncthreads();                                   // table loaded / previous image stored
+        for (int pi = tid; pi < ncb * ppc; pi += 256) {
+            const int st = pi / ppc, pair = pi - st * ppc;
+            int r, kk;
+            pair_rk(pair, r, kk);
+            float* dsti = img + st * step_floats + (r >> 4) * 64 + kk * 16 + (r & 15);
+            const float* mine = stage + pi * kr;
+            const int* tp = ftab + (o.fold_swap ? a : a * o.fold_tsrc) * 4;
+            const int tstep = (o.fold_swap ? o.fold_tsrc : 1) * 4;
+            for (int bq = 0; bq < kt; ++bq, tp += tstep) {
+                float v = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = tp[i];
+                    if (k >= 0) v += mine[k];              // masked pairs staged zeros
+                }
+                dsti[bq * mt * 64] = v;
+            }
+        }
+        __syncthreads();
+        float* out = o.packed + o.g_woff[g + a] + (size_t)c40 * step_floats;
+        const int n = ncb * step_floats;
+        for (int i = tid; i < n; i += 256) out[i] = img[i];
+    }
 }
 
 extern "C" int hmvae_pack_weights_multi(const hmvae_pack_op* ops_dev, int32_t n_ops, int32_t total_blocks,
-                                        int32_t max_kt_mt, hmvae_stream_t stream) {
-    if (!ops_dev || n_ops <= 0 || total_blocks <= 0 || max_kt_mt <= 0) return HMVAE_ERR_ARG;
-    const size_t lds = (size_t)max_kt_mt * 64 * sizeof(float);
+                                        int32_t max_lds_floats, hmvae_stream_t stream) {
+    if (!ops_dev || n_ops <= 0 || total_blocks <= 0 || max_lds_floats <= 0) return HMVAE_ERR_ARG;
+    const size_t lds = (size_t)max_lds_floats * sizeof(float);
     if (lds > 64 * 1024) return HMVAE_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), lds, (hipStream_t)stream, ops_dev, n_ops);
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;

@@ -18,6 +18,7 @@ import os as _os
 
 USE_V2 = _os.environ.get("HMVAE_GEMM", "v2") != "v1"
 AUTOTUNE = _os.environ.get("HMVAE_AUTOTUNE", "1") != "0"
+FOLD = _os.environ.get("HMVAE_FOLD", "1") != "0"        # tap folding for convolutions over fewer positions than taps
 USE_V3 = _os.environ.get("HMVAE_V3", "1") != "0"        # let the autotuner consider the v3 window kernel
 # optional JSON file that persists the autotuner's choices between processes (profiling runs reuse it so the trace
 # holds only the launches of the timed steps)
@@ -60,9 +61,12 @@ def _dev(arr, device):
 class _Side:
     """One gather-GEMM direction: groups + position pairs + row maps (all on the device)."""
 
-    def __init__(self, device, groups, pairs, chan_row_base, row_dst_base, bias_rows, src_ts, dst_ts, dense_strides):
+    def __init__(self, device, groups, pairs, chan_row_base, row_dst_base, bias_rows, src_ts, dst_ts, dense_strides,
+                 fold=None):
         self.g = groups
         self.device = device
+        # fold = (fold_taps, fold_mod, fold_swap, t_src): the packed matrix is the tap-folded effective one (hmvae.h)
+        self.fold = None if fold is None else (_dev(fold[0], device), int(fold[1]), int(fold[2]), int(fold[3]), int(fold[4]))
         self.row_id = _dev(groups.row_id, device)
         self.chan_id = _dev(groups.chan_id, device)
         self.g_nc4 = _dev(groups.g_nc4, device)
@@ -98,21 +102,29 @@ class _Side:
         self.wp = torch.zeros(max(groups.packed_size, 1), dtype=torch.float32, device=device)
 
     def pack(self, dense):
-        lib = _lib.load()
-        g = self.g
-        rs, cs, ts = self.strides
-        _lib.check(lib.hmvae_pack_weights(_lib.ptr(dense), _lib.ptr(self.wp), _lib.ptr(self.g_nc4), _lib.ptr(self.g_woff),
-                                          _lib.ptr(self.g_choff), _lib.ptr(self.chan_id), _lib.ptr(self.row_id),
-                                          _lib.ptr(self.g_okoff), _lib.ptr(self.pair_ok), g.n_groups, int(g.g_nc4.max()),
-                                          g.mt, g.kt, rs, cs, ts, 0, _lib.stream()), "pack_weights")
+        MultiPack(self.device).run([(self, dense)])
 
     def pack_op(self, dense, block_start):
         """Descriptor for hmvae_pack_weights_multi."""
         g = self.g
         rs, cs, ts = self.strides
+        f = self.fold
         return _lib.PackOp(_lib.ptr(dense), _lib.ptr(self.wp), _lib.ptr(self.g_nc4), _lib.ptr(self.g_woff),
                            _lib.ptr(self.g_choff), _lib.ptr(self.chan_id), _lib.ptr(self.row_id), _lib.ptr(self.g_okoff),
-                           _lib.ptr(self.pair_ok), g.n_groups, int(g.g_nc4.max()), g.mt, g.kt, rs, cs, ts, int(block_start))
+                           _lib.ptr(self.pair_ok), g.n_groups, int(g.g_nc4.max()), g.mt, g.kt, rs, cs, ts, int(block_start),
+                           None if f is None else _lib.ptr(f[0]), 1 if f is None else f[1], 0 if f is None else f[2],
+                           1 if f is None else f[3], 0 if f is None else f[4])
+
+    def pack_lds_floats(self):
+        g = self.g
+        n = 4 * g.kt * g.mt * 64
+        if self.fold is not None:
+            n += 4 * g.mt * 64 * (self.fold[4] + 1) + int(self.fold[0].numel())
+        return n
+
+    def pack_blocks(self):
+        n = self.g.n_groups if self.fold is None else self.g.n_groups // self.fold[1]
+        return n * (-(-int(self.g.g_nc4.max()) // 4))
 
     def items_for(self, np_):
         if np_ not in self._items:
@@ -308,7 +320,7 @@ class MaskedGemm:
     """
 
     def __init__(self, device, w_shape, rows_f, chans_f, rows_b, chans_b, pairs_f, pairs_b, x_base, y_base, x_ts, y_ts,
-                 conv_geom=None, bias_rows=None):
+                 conv_geom=None, bias_rows=None, fold_t=None):
         n_rows, n_chan, kt = w_shape
         self.w_shape = tuple(int(v) for v in w_shape)
         self.kt = int(kt)
@@ -316,12 +328,31 @@ class MaskedGemm:
         x_base = np.asarray(x_base, dtype=np.int64)
         y_base = np.asarray(y_base, dtype=np.int64)
         gf = P.make_groups(rows_f, chans_f, kt)
-        self.fwd = _Side(device, gf, pairs_f, x_base, y_base, bias_rows, x_ts, y_ts, (n_chan * kt, kt, 1))
+        gb = P.make_groups(rows_b, chans_b, kt) if rows_b is not None else None
+        fold_taps = P.fold_table(pairs_f, fold_t[0]) if fold_t is not None else None
+        self.folded = fold_taps is not None
         self.bwd = None
-        if rows_b is not None:
-            gb = P.make_groups(rows_b, chans_b, kt)
-            # transposed: "rows" are forward channels, "channels" are forward rows
-            self.bwd = _Side(device, gb, pairs_b, y_base, x_base, None, y_ts, x_ts, (kt, n_chan * kt, 1))
+        if not self.folded:
+            self.fwd = _Side(device, gf, pairs_f, x_base, y_base, bias_rows, x_ts, y_ts, (n_chan * kt, kt, 1))
+            if rows_b is not None:
+                # transposed: "rows" are forward channels, "channels" are forward rows
+                self.bwd = _Side(device, gb, pairs_b, y_base, x_base, None, y_ts, x_ts, (kt, n_chan * kt, 1))
+        else:
+            # Tap folding (hmvae.h, hmvae_pack_op): per output position p the layer is a dense map over the t_src source
+            # positions with effective weights Weff[p][q].  As a MaskedGemm: one "position", effective rows (row, p),
+            # t_src "taps" (q) forward;  effective rows (chan, q), t_dst "taps" (p) for the transposed side.
+            t_src, t_dst = int(fold_t[0]), int(fold_t[1])
+            assert t_dst == len(pairs_f)
+            br = np.arange(n_rows, dtype=np.int64) if bias_rows is None else np.asarray(bias_rows, dtype=np.int64)
+            gfe = P.fold_groups(gf, t_dst, t_src)
+            ydst = (y_base[:, None] + np.arange(t_dst)[None, :] * y_ts).reshape(-1)
+            self.fwd = _Side(device, gfe, [[(q, q) for q in range(t_src)]], x_base, ydst, np.repeat(br, t_dst), x_ts, y_ts,
+                             (n_chan * kt, kt, 1), fold=(fold_taps, t_dst, 0, t_src, kt))
+            if rows_b is not None:
+                gbe = P.fold_groups(gb, t_src, t_dst)
+                xdst = (x_base[:, None] + np.arange(t_src)[None, :] * x_ts).reshape(-1)
+                self.bwd = _Side(device, gbe, [[(p, p) for p in range(t_dst)]], y_base, xdst, None, y_ts, x_ts,
+                                 (kt, n_chan * kt, 1), fold=(fold_taps, t_src, 1, t_src, kt))
         # weight gradient tiles: forward grouping, or (masked convs) a grouping keyed by input block whose tiles have
         # several 16-row pieces per activation load and no union waste
         gw = gf
@@ -353,9 +384,8 @@ class MaskedGemm:
         self.wg_transposed = False
         self._ev_f = self._ev_b = None
         ge = self.geom
-        if (self.bwd is not None and ge["stride"] == 1 and ge["pad_mode"] == _lib.PAD_REFLECT and ge["pad"] > 0
-                and _os.environ.get("HMVAE_WGRAD_T", "1") != "0"):
-            gb = self.bwd.g
+        if (self.bwd is not None and not self.folded and ge["stride"] == 1 and ge["pad_mode"] == _lib.PAD_REFLECT
+                and ge["pad"] > 0 and _os.environ.get("HMVAE_WGRAD_T", "1") != "0"):
             tg_t, tc_t, nc_t = gb.wgrad_tiles()
             cost_std = self.n_tiles * gw.mt * ge["t_dst"]
             cost_tr = len(tg_t) * gb.mt * (ge["t_src"] + 2 * ge["pad"])
@@ -491,8 +521,10 @@ def conv_gemm(device, neigh, cin, cout, kt, stride, pad, pad_mode, t_in, need_dx
     y_base = oc * t_out
     geom = dict(t_dst=t_out, t_src=t_in, stride=stride, pad=pad,
                 pad_mode=_lib.PAD_REFLECT if mode == "reflect" else _lib.PAD_ZEROS)
+    # short sequences: fewer source positions than taps -> fold the taps into per-position-pair weights
+    fold_t = (t_in, t_out) if (FOLD and t_in < kt and t_in <= 32 and t_out * t_in <= 254) else None
     op = MaskedGemm(device, (cout, cin, kt), rows_f, chans_f, rows_b, chans_b, pairs_f, pairs_b, x_base, y_base, 1, 1,
-                    conv_geom=geom)
+                    conv_geom=geom, fold_t=fold_t)
     op.t_in, op.t_out = t_in, t_out
     return op
 
@@ -668,8 +700,8 @@ class MultiPack:
             kmax = 1
             for i, (s, w) in enumerate(sides_and_weights):
                 arr[i] = s.pack_op(w, start)
-                start += s.g.n_groups * int(s.g.g_nc4.max())
-                kmax = max(kmax, s.g.kt * s.g.mt)
+                start += s.pack_blocks()
+                kmax = max(kmax, s.pack_lds_floats())
             self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
             self.n_ops, self.total, self.kmax, self.key = len(sides_and_weights), start, kmax, key
         _lib.check(_lib.load().hmvae_pack_weights_multi(self.table.data_ptr(), self.n_ops, self.total, self.kmax,

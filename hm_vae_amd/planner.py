@@ -463,3 +463,37 @@ def build_stream_schedule(unit_steps, unit_cost, n_workers, min_steps=3):
                 n_parts += 1
     return (np.asarray(segs, dtype=np.int64).reshape(-1, 4), np.asarray(worker_seg, dtype=np.int64).reshape(-1, 2),
             np.asarray(fixups, dtype=np.int64).reshape(-1, 3), n_parts)
+
+
+def fold_table(pairs_f, t_src):
+    """fold_taps[(p*t_src + q)*4 + i]: the (<= 4) taps through which output position p reads source position q (-1 pad).
+    None when some (p, q) needs more than 4."""
+    t_dst = len(pairs_f)
+    tab = -np.ones((t_dst * t_src, 4), dtype=np.int32)
+    cnt = np.zeros(t_dst * t_src, dtype=np.int64)
+    for p, lst in enumerate(pairs_f):
+        for q, tap in lst:
+            i = p * t_src + q
+            if cnt[i] >= 4:
+                return None
+            tab[i, cnt[i]] = tap
+            cnt[i] += 1
+    return tab.reshape(-1)
+
+
+def fold_groups(gs, mod, kt_eff):
+    """Groups of the tap-folded matrix: group g*mod + a holds the rows of group g of `gs` at position a (effective row
+    id = row*mod + a), same channel list and mask; kt_eff effective taps."""
+    rows_per = 16 * gs.mt
+    rid = gs.row_id.reshape(gs.n_groups, rows_per)
+    groups, row_chans = [], {}
+    for gi in range(gs.n_groups):
+        rows = [int(r) for r in rid[gi] if r >= 0]
+        nch = int(gs.g_nch[gi])
+        chans = [int(c) for c in gs.chan_id[gs.g_choff[gi]:gs.g_choff[gi] + nch]]
+        ok = gs.pair_ok[gs.g_okoff[gi]:gs.g_okoff[gi] + rows_per * int(gs.g_nc4[gi]) * 4].reshape(rows_per, -1)
+        for a in range(mod):
+            groups.append(([r * mod + a for r in rows], chans))
+            for ri, r in enumerate(rows):
+                row_chans[r * mod + a] = frozenset(c for ci, c in enumerate(chans) if ok[ri, ci])
+    return GroupSet(gs.mt, groups, kt_eff, row_chans)

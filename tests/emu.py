@@ -14,6 +14,9 @@ def emu_pack(side, dense):
     dense = dense.reshape(-1)
     wp = np.zeros(max(g.packed_size, 1), dtype=np.float32)
     row_id = g.row_id.reshape(g.n_groups, g.mt * 16)
+    fold = getattr(side, "fold", None)
+    if fold is not None:
+        taps, mod, swap, tsrc = _np(fold[0]).reshape(-1, 4), fold[1], fold[2], fold[3]
     for gi in range(g.n_groups):
         for c4 in range(int(g.g_nc4[gi])):
             for tap in range(g.kt):
@@ -25,7 +28,12 @@ def emu_pack(side, dense):
                             ok = g.pair_ok[g.g_okoff[gi] + (mt * 16 + m) * (int(g.g_nc4[gi]) * 4) + c4 * 4 + kk]
                             if rid >= 0 and cid >= 0 and ok:
                                 idx = g.g_woff[gi] + ((c4 * g.kt + tap) * g.mt + mt) * 64 + kk * 16 + m
-                                wp[idx] = dense[rid * rs + cid * cs + tap * ts]
+                                if fold is None:
+                                    wp[idx] = dense[rid * rs + cid * cs + tap * ts]
+                                else:       # tap folding (hmvae_pack_op): sum of the taps connecting (p, q)
+                                    real, a = divmod(int(rid), mod)
+                                    pq = tap * tsrc + a if swap else a * tsrc + tap
+                                    wp[idx] = np.float32(sum(dense[real * rs + cid * cs + k * ts] for k in taps[pq] if k >= 0))
     return wp
 
 

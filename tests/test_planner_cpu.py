@@ -44,6 +44,9 @@ def test_topology_matches_oracle():
     dict(level=1, ci=3, co=2, K=3, stride=1, T=4, mode="reflect"),
     dict(level=2, ci=4, co=8, K=5, stride=1, T=6, mode="zeros"),
     dict(level=3, ci=4, co=20, K=3, stride=2, T=4, mode="reflect"),     # all-neighbour level, rows > 16
+    dict(level=3, ci=3, co=5, K=15, stride=1, T=8, mode="reflect"),     # fewer positions than taps: tap folding (dec0)
+    dict(level=3, ci=2, co=6, K=15, stride=2, T=8, mode="reflect"),     # ... strided (enc3)
+    dict(level=2, ci=2, co=3, K=7, stride=1, T=4, mode="zeros"),        # ... zero padding
 ])
 def test_conv_tables_reproduce_oracle(case):
     torch.manual_seed(case["level"])
@@ -78,16 +81,18 @@ def test_conv_tables_reproduce_oracle(case):
     dw = np.zeros((cout, cin, K), dtype=np.float32)
     emu_wgrad(op, to_soa(gy), to_soa(x.detach()), dw)
     assert rel_err(dw, (w.grad * mask).numpy()) < 1e-5
-    # grouping sanity: every masked (row, chan) pair is covered exactly once
+    assert op.folded == (T < K)
+    # grouping sanity: every masked (row, chan) pair is covered exactly once (per output position when folded)
     g = op.fwd.g
-    cover = np.zeros((cout, cin), dtype=np.int32)
+    cover = np.zeros((cout * (T_out if op.folded else 1), cin), dtype=np.int32)
+    mask_rows = np.repeat(mask[:, :, 0].numpy(), T_out if op.folded else 1, axis=0)
     rid = g.row_id.reshape(g.n_groups, -1)
     for gi in range(g.n_groups):
         rows = rid[gi][rid[gi] >= 0]
         ch = g.chan_id[g.g_choff[gi]:g.g_choff[gi] + g.g_nc4[gi] * 4]
         ch = ch[ch >= 0]
         cover[np.ix_(rows, ch)] += 1
-    assert (cover[mask[:, :, 0].numpy() > 0] == 1).all()
+    assert (cover[mask_rows > 0] == 1).all()
     assert cover.max() == 1
 
 
