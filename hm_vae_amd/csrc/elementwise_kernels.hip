@@ -230,9 +230,10 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const float* __restrict__
     const int base = rows[o];
     float s = 0.f;
     const int nq = n_cols >> 2;
-    for (int k = 0; k < rows_per_out; ++k) {
+    // the 4 waves take different rows (independent loads in flight), lanes take 16-byte pieces of a row
+    for (int k = threadIdx.x >> 6; k < rows_per_out; k += 4) {
         const f32x4* p = (const f32x4*)(src + (size_t)(base + k * row_step) * n_cols);
-        for (int q = threadIdx.x; q < nq; q += 256) {
+        for (int q = threadIdx.x & 63; q < nq; q += 64) {
             const f32x4 v = p[q];
             s += (v[0] + v[1]) + (v[2] + v[3]);
         }
@@ -261,9 +262,9 @@ __global__ __launch_bounds__(256) void row_sums_multi_kernel(const hmvae_rowsum_
     const int base = op.rows[o];
     float s = 0.f;
     const int nq = op.n_cols >> 2;
-    for (int k = 0; k < op.rows_per_out; ++k) {
+    for (int k = threadIdx.x >> 6; k < op.rows_per_out; k += 4) {
         const f32x4* p = (const f32x4*)(op.src + (size_t)(base + k * op.row_step) * op.n_cols);
-        for (int q = threadIdx.x; q < nq; q += 256) {
+        for (int q = threadIdx.x & 63; q < nq; q += 64) {
             const f32x4 v = p[q];
             s += (v[0] + v[1]) + (v[2] + v[3]);
         }

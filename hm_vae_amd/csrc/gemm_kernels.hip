@@ -403,57 +403,40 @@ extern "C" int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t str
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }
 
-__global__ __launch_bounds__(256) void wreduce_kernel(hmvae_wreduce_desc d) {
+// One workgroup per tile (strided over the tiles when the grid is smaller): the tile's group and first column are
+// uniform, a thread keeps one of the 64 columns -- its (channel, tap) split is done once -- and walks the rows, so per
+// element there is one mask byte, n_split coalesced slab reads and one store (no per-element divisions or table walks).
+__device__ __forceinline__ void wreduce_body(const hmvae_wreduce_desc& d, int blk, int nblk) {
     const int rows = d.mt * 16;
-    const long long per_tile = (long long)rows * 64;
-    const long long total = per_tile * d.n_tiles;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int tile = (int)(idx / per_tile);
-        const int rem = (int)(idx - (long long)tile * per_tile);
-        const int row = rem >> 6, col = rem & 63;
+    const int per_tile = rows * 64;
+    const int col = threadIdx.x & 63;
+    const int r0 = threadIdx.x >> 6;
+    for (int tile = blk; tile < d.n_tiles; tile += nblk) {
         const int g = d.tile_g[tile];
         const int gc = d.tile_col0[tile] + col;
         if (gc >= d.g_ncols[g]) continue;
-        const int rid = d.row_id[g * rows + row];
-        if (rid < 0) continue;
         const int c = gc / d.kt;
         const int tap = gc - c * d.kt;
         const int cid = d.chan_id[d.g_choff[g] + c];
         if (cid < 0) continue;
-        if (!d.pair_ok[d.g_okoff[g] + row * (d.g_nc4[g] * 4) + c]) continue;
-        float s = 0.f;
-        for (int sp = 0; sp < d.n_split; ++sp) s += d.slab[((size_t)sp * d.n_tiles + tile) * per_tile + rem];
-        float* o = d.dense + (size_t)rid * d.row_stride + (size_t)cid * d.chan_stride + tap;
-        if (d.accumulate) s += *o;
-        *o = s;
+        const unsigned char* okp = d.pair_ok + d.g_okoff[g] + c;
+        const int ok_stride = d.g_nc4[g] * 4;
+        float* ocol = d.dense + (size_t)cid * d.chan_stride + tap;
+        const float* sl = d.slab + (size_t)tile * per_tile + col;
+        const size_t split_stride = (size_t)d.n_tiles * per_tile;
+        for (int row = r0; row < rows; row += 4) {
+            const int rid = d.row_id[g * rows + row];
+            if (rid < 0 || !okp[row * ok_stride]) continue;
+            float s = 0.f;
+            for (int sp = 0; sp < d.n_split; ++sp) s += sl[sp * split_stride + row * 64];
+            float* o = ocol + (size_t)rid * d.row_stride;
+            if (d.accumulate) s += *o;
+            *o = s;
+        }
     }
 }
 
-__device__ __forceinline__ void wreduce_body(const hmvae_wreduce_desc& d, int blk, int nblk) {
-    const int rows = d.mt * 16;
-    const long long per_tile = (long long)rows * 64;
-    const long long total = per_tile * d.n_tiles;
-    for (long long idx = (long long)blk * 256 + threadIdx.x; idx < total; idx += (long long)nblk * 256) {
-        const int tile = (int)(idx / per_tile);
-        const int rem = (int)(idx - (long long)tile * per_tile);
-        const int row = rem >> 6, col = rem & 63;
-        const int g = d.tile_g[tile];
-        const int gc = d.tile_col0[tile] + col;
-        if (gc >= d.g_ncols[g]) continue;
-        const int rid = d.row_id[g * rows + row];
-        if (rid < 0) continue;
-        const int c = gc / d.kt;
-        const int tap = gc - c * d.kt;
-        const int cid = d.chan_id[d.g_choff[g] + c];
-        if (cid < 0) continue;
-        if (!d.pair_ok[d.g_okoff[g] + row * (d.g_nc4[g] * 4) + c]) continue;
-        float s = 0.f;
-        for (int sp = 0; sp < d.n_split; ++sp) s += d.slab[((size_t)sp * d.n_tiles + tile) * per_tile + rem];
-        float* o = d.dense + (size_t)rid * d.row_stride + (size_t)cid * d.chan_stride + tap;
-        if (d.accumulate) s += *o;
-        *o = s;
-    }
-}
+__global__ __launch_bounds__(256) void wreduce_kernel(hmvae_wreduce_desc d) { wreduce_body(d, blockIdx.x, gridDim.x); }
 
 __global__ __launch_bounds__(256) void wreduce_multi_kernel(const hmvae_wreduce_desc* __restrict__ descs,
                                                             const int* __restrict__ block_start, int n_ops) {
@@ -474,9 +457,7 @@ extern "C" int hmvae_wgrad_reduce_multi(const hmvae_wreduce_desc* descs_dev, con
 
 extern "C" int hmvae_wgrad_reduce(const hmvae_wreduce_desc* desc, hmvae_stream_t stream) {
     if (!desc || !desc->slab || !desc->dense || !desc->pair_ok || desc->n_tiles <= 0) return HMVAE_ERR_ARG;
-    const long long total = (long long)desc->n_tiles * desc->mt * 16 * 64;
-    long long nb = (total + 255) / 256;
-    if (nb > 8192) nb = 8192;
+    const int nb = desc->n_tiles < 16384 ? desc->n_tiles : 16384;
     hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *desc);
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }

@@ -463,6 +463,9 @@ class MaskedGemm:
                                 _lib.ptr(tb["pair_ok"]), self.n_tiles, g.mt, g.kt, ns, n_chan * kt, kt,
                                 1 if accumulate else 0)
 
+    def reduce_rows(self):
+        return (self.bwd.g.mt if self.wg_transposed else self.wg.mt) * 16
+
     def reduce_elems(self):
         if self.wg_transposed:
             return self.n_tiles_t * self.bwd.g.mt * 16 * 64
@@ -724,7 +727,7 @@ class MultiReduce:
             starts = [0]
             for i, (op, slab, dw) in enumerate(reduces):
                 descs[i] = op.reduce_desc(slab, dw, bp)
-                nb = min(2048, max(1, (op.reduce_elems() + 255) // 256))
+                nb = min(4096, max(1, op.reduce_elems() // (op.reduce_rows() * 64)))
                 starts.append(starts[-1] + nb)
             self.rd = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device)
             self.rs = torch.tensor(starts, dtype=torch.int32, device=self.device)
