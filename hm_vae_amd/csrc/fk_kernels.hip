@@ -13,6 +13,7 @@
 //   p_j = p_par + G_par·off_j,  G_j = G_par·R_j
 //   H_j = sum_{c child of j} ( H_c·R_c^T + S_c ⊗ off_c ),   dR_j = dR_j(direct) + G_par^T·H_j
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "hmvae.h"
 
 namespace {
@@ -460,33 +461,131 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void decode_tail_loss_kernel(const float* __restrict__ dec, const float* __restrict__ g6,
-                                                              const float* __restrict__ gR, const float* __restrict__ gP,
-                                                              const float* __restrict__ offs, int T, int B, int bp,
-                                                              float c6, float cR, float cP, float* __restrict__ ddec,
-                                                              float* __restrict__ partial) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
+// One workgroup = 64 frames x 4 waves.  A frame's work is split by SUBTREE over the waves (a wave runs one role, so
+// there is no divergence and every load/store stays a 256-byte row segment): one thread per frame left 3 of 4 SIMDs
+// without a wave at the 16 384 frames of the training step and ran ~120 us on the critical path.
+//   wave 1: the legs (subtrees of joints 1 and 2, hanging off the root)
+//   wave 2 / 3: the left / right arm (subtrees of 13 / 14, hanging off joint 9)
+//   wave 0: the head (subtree of 12), then -- after one barrier -- the trunk 9 -> 6 -> 3 -> 0 with the limbs' sums
+// Every wave recomputes the trunk's forward chain it needs (<= 4 lifts + 3 products); a limb hands its parent
+// S = sum of dP over the subtree and H = H_c R_c^T + S (x) off_c through LDS (12 floats per frame).
+__global__ __launch_bounds__(256) void decode_tail_loss_kernel(const float* __restrict__ dec, const float* __restrict__ g6,
+                                                               const float* __restrict__ gR, const float* __restrict__ gP,
+                                                               const float* __restrict__ offs, int T, int B, int bp,
+                                                               float c6, float cR, float cP, float* __restrict__ ddec,
+                                                               float* __restrict__ partial) {
+    __shared__ float xch[4][12][64];                  // [limb][S(3) + H(9)][frame]
+    __shared__ float psum[4][3];
+    const int lane = threadIdx.x & 63;
+    const int role = threadIdx.x >> 6;                // wave-uniform
+    const int b = blockIdx.x * 64 + lane;
     const int t = blockIdx.y;
     const size_t rs = (size_t)T * bp;
     const size_t o = (size_t)t * bp + b;
-    float s6 = 0.f, sR = 0.f, sP = 0.f;
-    if (b < B) {
-        TailLoss io{dec + o, g6 + o, gR + o, gP + o, offs, ddec + o, rs, 0.f, 0.f, 0.f, c6, cR, cP};
-        fk_bwd_root(io);
-        s6 = io.s6;
-        sR = io.sR;
-        sP = io.sP;
-    } else if (b < bp) {
+    const bool live = b < B;
+    TailLoss io{dec + o, g6 + o, gR + o, gP + o, offs, ddec + o, rs, 0.f, 0.f, 0.f, c6, cR, cP};
+    auto hand_over = [&](int slot, const V3& S, const M3& H) {
+        xch[slot][0][lane] = S.x;
+        xch[slot][1][lane] = S.y;
+        xch[slot][2][lane] = S.z;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) xch[slot][3 + i][lane] = H.a[i];
+    };
+    auto limb = [&](auto child, const M3& G, V3 P, V3& S, M3& H) {      // add subtree `child` to its parent's (S, H)
+        constexpr int C = decltype(child)::value;
+        V3 Sc;
+        M3 Hc;
+        fk_bwd_node<C>(G, P, io, Sc, Hc);
+        S = S + Sc;
+        add_m(H, Hc);
+        add_outer(H, Sc, io.off(C));
+    };
+    M3 G0, G3, G6, G9;
+    V3 P0, P3, P6, P9;
+    if (live) {
+        // forward along the trunk (role 1 only needs the root)
+        io.rot(0, G0);
+        P0 = io.off(0);
+        if (role != 1) {
+            M3 R;
+            io.rot(3, R);
+            P3 = P0 + mulv(G0, io.off(3));
+            G3 = mul(G0, R);
+            io.rot(6, R);
+            P6 = P3 + mulv(G3, io.off(6));
+            G6 = mul(G3, R);
+            io.rot(9, R);
+            P9 = P6 + mulv(G6, io.off(9));
+            G9 = mul(G6, R);
+        }
+        V3 S = {0.f, 0.f, 0.f};
+        M3 H;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) H.a[i] = 0.f;
+        if (role == 1) {
+            limb(std::integral_constant<int, 1>{}, G0, P0, S, H);
+            limb(std::integral_constant<int, 2>{}, G0, P0, S, H);
+        } else if (role == 2) {
+            limb(std::integral_constant<int, 13>{}, G9, P9, S, H);
+        } else if (role == 3) {
+            limb(std::integral_constant<int, 14>{}, G9, P9, S, H);
+        } else {
+            limb(std::integral_constant<int, 12>{}, G9, P9, S, H);
+        }
+        hand_over(role, S, H);
+    } else if (b < bp && role == 0) {
         for (int r = 0; r < NJ * 6; ++r) ddec[o + (size_t)r * rs] = 0.f;   // padded batch columns carry zero gradient
     }
-    s6 = wave_sum_f(s6);
-    sR = wave_sum_f(sR);
-    sP = wave_sum_f(sP);
-    if (threadIdx.x == 0) {
+    __syncthreads();
+    if (role == 0 && live) {
+        // trunk, leaves to root: node J with the sums (S, H) over its children
+        auto node = [&](int J, const M3& Gp, const M3& R, V3 P, V3& S, M3& H, bool root) {
+            const V3 gp = io.grad_P(J, P);
+            S = S + gp;
+            M3 dR;
+            io.grad_R(J, R, dR);
+            add_m(dR, root ? H : mul_tn(Gp, H));
+            io.emit(J, dR);
+            return mul_nt(H, R);                       // H R^T: what the parent's H receives (plus S (x) off_J)
+        };
+        auto take = [&](int slot, V3& S, M3& H) {
+            S = S + V3{xch[slot][0][lane], xch[slot][1][lane], xch[slot][2][lane]};
+#pragma unroll
+            for (int i = 0; i < 9; ++i) H.a[i] += xch[slot][3 + i][lane];
+        };
+        V3 S = {0.f, 0.f, 0.f};
+        M3 H, R;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) H.a[i] = 0.f;
+        take(0, S, H);                                 // head, left arm, right arm hang off joint 9
+        take(2, S, H);
+        take(3, S, H);
+        io.rot(9, R);
+        M3 Hu = node(9, G6, R, P9, S, H, false);
+        H = Hu;
+        add_outer(H, S, io.off(9));
+        io.rot(6, R);
+        Hu = node(6, G3, R, P6, S, H, false);
+        H = Hu;
+        add_outer(H, S, io.off(6));
+        io.rot(3, R);
+        Hu = node(3, G0, R, P3, S, H, false);
+        H = Hu;
+        add_outer(H, S, io.off(3));
+        take(1, S, H);                                 // the legs hang off the root
+        io.rot(0, R);
+        node(0, R, R, P0, S, H, true);
+    }
+    const float s6 = wave_sum_f(live ? io.s6 : 0.f), sR = wave_sum_f(live ? io.sR : 0.f), sP = wave_sum_f(live ? io.sP : 0.f);
+    if (lane == 0) {
+        psum[role][0] = s6;
+        psum[role][1] = sR;
+        psum[role][2] = sP;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
         float* p = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3;
-        p[0] = s6;
-        p[1] = sR;
-        p[2] = sP;
+        p[threadIdx.x] = (psum[0][threadIdx.x] + psum[1][threadIdx.x]) + (psum[2][threadIdx.x] + psum[3][threadIdx.x]);
     }
 }
 
@@ -537,7 +636,7 @@ extern "C" int hmvae_decode_tail_loss(const float* dec_out, const float* gt6d, c
                                       int32_t* n_blocks_out, hmvae_stream_t stream) {
     if (!dec_out || !gt6d || !gtR || !gtP || !offsets || !d_dec_out || !partial) return HMVAE_ERR_ARG;
     if (T <= 0 || T > 65535 || B <= 0 || bp < B || (bp & 63)) return HMVAE_ERR_ARG;
-    dim3 grid(bp / 64, T), block(64);
+    dim3 grid(bp / 64, T), block(256);
     if (n_blocks_out) *n_blocks_out = (int32_t)(grid.x * grid.y);
     hipLaunchKernelGGL(decode_tail_loss_kernel, grid, block, 0, (hipStream_t)stream, dec_out, gt6d, gtR, gtP, offsets, T, B,
                        bp, 2.f * scale_6d, 2.f * scale_rot, 2.f * scale_pos, d_dec_out, partial);

@@ -403,15 +403,17 @@ extern "C" int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t str
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }
 
-// One workgroup per tile (strided over the tiles when the grid is smaller): the tile's group and first column are
-// uniform, a thread keeps one of the 64 columns -- its (channel, tap) split is done once -- and walks the rows, so per
+// One workgroup per (tile, 16-row piece), strided when the grid is smaller: the tile's group and first column are
+// uniform, a thread keeps one of the 64 columns -- its (channel, tap) split is done once -- and 4 of the 16 rows, so per
 // element there is one mask byte, n_split coalesced slab reads and one store (no per-element divisions or table walks).
 __device__ __forceinline__ void wreduce_body(const hmvae_wreduce_desc& d, int blk, int nblk) {
     const int rows = d.mt * 16;
     const int per_tile = rows * 64;
     const int col = threadIdx.x & 63;
     const int r0 = threadIdx.x >> 6;
-    for (int tile = blk; tile < d.n_tiles; tile += nblk) {
+    const size_t split_stride = (size_t)d.n_tiles * per_tile;
+    for (int work = blk; work < d.n_tiles * d.mt; work += nblk) {
+        const int tile = work / d.mt, piece = work - tile * d.mt;
         const int g = d.tile_g[tile];
         const int gc = d.tile_col0[tile] + col;
         if (gc >= d.g_ncols[g]) continue;
@@ -423,8 +425,9 @@ __device__ __forceinline__ void wreduce_body(const hmvae_wreduce_desc& d, int bl
         const int ok_stride = d.g_nc4[g] * 4;
         float* ocol = d.dense + (size_t)cid * d.chan_stride + tap;
         const float* sl = d.slab + (size_t)tile * per_tile + col;
-        const size_t split_stride = (size_t)d.n_tiles * per_tile;
-        for (int row = r0; row < rows; row += 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = piece * 16 + r0 + 4 * i;
             const int rid = d.row_id[g * rows + row];
             if (rid < 0 || !okp[row * ok_stride]) continue;
             float s = 0.f;
@@ -457,7 +460,8 @@ extern "C" int hmvae_wgrad_reduce_multi(const hmvae_wreduce_desc* descs_dev, con
 
 extern "C" int hmvae_wgrad_reduce(const hmvae_wreduce_desc* desc, hmvae_stream_t stream) {
     if (!desc || !desc->slab || !desc->dense || !desc->pair_ok || desc->n_tiles <= 0) return HMVAE_ERR_ARG;
-    const int nb = desc->n_tiles < 16384 ? desc->n_tiles : 16384;
+    const int nw = desc->n_tiles * desc->mt;
+    const int nb = nw < 16384 ? nw : 16384;
     hipLaunchKernelGGL(wreduce_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *desc);
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }

@@ -727,7 +727,7 @@ class MultiReduce:
             starts = [0]
             for i, (op, slab, dw) in enumerate(reduces):
                 descs[i] = op.reduce_desc(slab, dw, bp)
-                nb = min(4096, max(1, op.reduce_elems() // (op.reduce_rows() * 64)))
+                nb = min(8192, max(1, op.reduce_elems() // 1024))
                 starts.append(starts[-1] + nb)
             self.rd = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device)
             self.rs = torch.tensor(starts, dtype=torch.int32, device=self.device)
