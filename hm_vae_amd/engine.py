@@ -19,6 +19,8 @@ from . import _lib, ops, topology
 # 1: all slab->gradient reductions and bias sums as two launches after the backward chain (fewer launches, but they
 # then sit on the critical path; measured slower than overlapping them on the side streams)
 MULTI_REDUCE = _os0.environ.get("HMVAE_MULTI_REDUCE", "0") == "1"
+# 1: targets (transposes + ground-truth FK), noise and the non-encoder weight layouts run on a side stream beside the encoder
+EARLY_SIDE = _os0.environ.get("HMVAE_EARLY_SIDE", "1") != "0"
 
 
 class VaePlan:
@@ -118,6 +120,9 @@ class VaeEngine:
         self._side = None
         self._pack_stream = None
         self._multipack = None
+        self._multipack_late = None
+        self._late_packs = []
+        self._early = None
         self._multired = None
         import os as _os
         self.overlap = _os.environ.get("HMVAE_OVERLAP", "1") != "0"
@@ -266,7 +271,7 @@ class VaeEngine:
         lst += [(self.dec_conv[i], P[dconv[i] + ".weight"]) for i in range(L)]
         return lst
 
-    def pack_weights(self, side=True):
+    def pack_weights(self, side=True, defer_late=False):
         """Regather the dense weights into MFMA-fragment order (applies the neighbour mask, skeleton.py:96).
         With `side`, the ~23 small memory-bound pack kernels run on their own stream, forward layouts first in layer
         order and backward layouts after, each leaving an event its consumer waits on — so they hide under the
@@ -277,12 +282,20 @@ class VaeEngine:
         if not (side and self.overlap and self.pack_async):
             if self._multipack is None:
                 self._multipack = ops.MultiPack(self.device)
-            sw = []
+                self._multipack_late = ops.MultiPack(self.device)
+            # two launches: what the encoder needs right away, and the rest (decoder layouts, every transposed layout),
+            # which the early side stream packs while the encoder runs (train_step joins it before the decoder)
+            first, late = [], []
+            enc_ops = set(id(o) for o in self.enc_conv + self.enc_lin)
             for op, wt in lst:
-                sw.append((op.fwd, wt))
+                (first if (id(op) in enc_ops or not EARLY_SIDE) else late).append((op.fwd, wt))
                 if op.bwd is not None:
-                    sw.append((op.bwd, wt))
-            self._multipack.run(sw)
+                    (late if EARLY_SIDE else first).append((op.bwd, wt))
+            self._multipack.run(first)
+            self._late_packs = late
+            if not defer_late and late:          # callers outside train_step: everything now, on this stream
+                self._multipack_late.run(late)
+                self._late_packs = []
             return
         main = torch.cuda.current_stream()
         if self._pack_stream is None:
@@ -299,11 +312,22 @@ class VaeEngine:
     # ------------------------------------------------------------------------------------------
     # forward pieces
     # ------------------------------------------------------------------------------------------
+    def _early_stream(self):
+        main = torch.cuda.current_stream()
+        if self._early is None:
+            self._early = torch.cuda.Stream(device=self.device)
+        self._early.wait_stream(main)
+        return self._early
+
     def stage_batch(self, w, r6, rmat):
         """AoS (B,T,144)/(B,T,216) device tensors -> SoA inputs/targets; target joint positions by FK
         (seq_two_hier_sa_vae.py:343)."""
         B, T, bp = w["B"], self.p.T, w["bp"]
         ops.aos_to_soa(r6, w["X0"], B, T, 144, bp)
+        self.stage_targets(w, rmat)
+
+    def stage_targets(self, w, rmat):
+        B, T, bp = w["B"], self.p.T, w["bp"]
         ops.aos_to_soa(rmat, w["GR"], B, T, 216, bp)
         ops.fk_fwd(rmat, 9, self.offsets, 0, self.parents, B * T, None, w["pos_aos"])
         ops.aos_to_soa(w["pos_aos"], w["GP"], B, T, 72, bp)
@@ -347,23 +371,34 @@ class VaeEngine:
         bp = w["bp"]
         phase2 = iterations >= hp["iteration_interval"]
         sample = hp["kl_w"] != 0
+        self._late_packs = []
         if repack:
-            self.pack_weights()
-        self.stage_batch(w, r6, rmat)
-        self.encode(w, (0, L - 1))
-        # reparametrise in level order 0..L-1 so the generator is consumed like the reference (:359-391)
+            self.pack_weights(defer_late=True)
+        ops.aos_to_soa(r6, w["X0"], B, T, 144, bp)
+        # Off the critical path, on the early side stream while the encoder runs: the targets (transposes + FK of the
+        # ground truth, seq_two_hier_sa_vae.py:343), the noise of every level -- drawn in level order 0..L-1 so the
+        # generator is consumed like the reference (:359-391) -- and the weight layouts the encoder does not read.
+        early = self._early_stream() if (EARLY_SIDE and self.overlap) else None
         eps = []
-        for i in range(L):
+        with (torch.cuda.stream(early) if early is not None else contextlib.nullcontext()):
+            self.stage_targets(w, rmat)
+            for i in range(L):
+                k, d = p.edge_num[i + 1], p.lat_dim[i]
+                if eps_list is not None:
+                    e = eps_list[i]
+                elif sample:
+                    e = torch.randn(B * k, d, device=self.device)
+                else:
+                    e = None
+                eps.append(e)
+            if self._late_packs:
+                self._multipack_late.run(self._late_packs)
+        self.encode(w, (0, L - 1))
+        if early is not None:
+            torch.cuda.current_stream().wait_stream(early)
+        for i in (0, L - 1):
             k, d = p.edge_num[i + 1], p.lat_dim[i]
-            if eps_list is not None:
-                e = eps_list[i]
-            elif sample:
-                e = torch.randn(B * k, d, device=self.device)
-            else:
-                e = None
-            eps.append(e)
-            if i in (0, L - 1):
-                ops.reparam_kl_fwd(w["ZD%d" % i], e, w["Z%d" % i], w["KLP%d" % i], k, d, B, bp, sample)
+            ops.reparam_kl_fwd(w["ZD%d" % i], eps[i], w["Z%d" % i], w["KLP%d" % i], k, d, B, bp, sample)
         self.decode_feats(w)
         n6, nR, nP = B * T * 144, B * T * 216, B * T * 72
         ops.decode_tail_loss(w["D%d" % (L - 1)], w["X0"], w["GR"], w["GP"], self.offsets, T, B, bp,
