@@ -47,6 +47,8 @@ json.dump({"tag": tag, "unit": "bytes per launch (mean over all launches of the 
           open(os.path.join(root, "profiles", "%s_traffic.json" % tag), "w"), indent=1)
 for f in glob.glob(os.path.join(root, "gpurun_out", "prof_%s_stats" % tag, "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(root, "profiles", "%s_kernel_stats.csv" % tag))
+for f in glob.glob(os.path.join(root, "gpurun_out", "prof_%s_serial" % tag, "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(root, "profiles", "%s_serial_kernel_stats.csv" % tag))
 for k, v in res.items():
     print("%-40s fetch(x2) %10.3f MB  write %10.3f MB  n=%d" % (k[:40], v["fetch_bytes_x2"] / 1e6, v["write_bytes"] / 1e6,
                                                                 v["launches_fetch_pass"]))
