@@ -382,6 +382,7 @@ class MaskedGemm:
         # weight-gradient orientation: rows = output channels (standard) or rows = input channels walked over the padded
         # positions (transposed; stride-1 reflect convs only).  Pick the one that issues fewer MFMAs.
         self.wg_transposed = False
+        self._split_tuned = {}
         self._ev_f = self._ev_b = None
         ge = self.geom
         if (self.bwd is not None and not self.folded and ge["stride"] == 1 and ge["pad_mode"] == _lib.PAD_REFLECT
@@ -430,17 +431,49 @@ class MaskedGemm:
         self._wait("b")
         self.bwd.run(dy, dx, bp, None, _lib.FLAG_ACCUM if accumulate else 0)
 
+    def _k_chunks(self, bp):
+        ge = self.geom
+        return ((ge["t_src"] + 2 * ge["pad"]) if self.wg_transposed else ge["t_dst"]) * (bp // 32)
+
+    def _split_heuristic(self, bp):
+        return P.pick_split(self.n_tiles_t if self.wg_transposed else self.n_tiles, self._k_chunks(bp))
+
+    def split_candidates(self, bp):
+        """Splits of the (position, batch) reduction worth timing: the grid is n_tiles * split workgroups of 4 waves and
+        its tail decides (1110 workgroups on 512 slots run 3 rounds, 1024 run 2)."""
+        h, kc = self._split_heuristic(bp), self._k_chunks(bp)
+        cand = sorted(set(max(1, min(c, kc // 2 if kc >= 2 else 1)) for c in
+                          (h, h - 1, h + 1, h + 2, (3 * h + 1) // 2, 2 * h, max(1, h // 2), max(1, (2 * h) // 3))))
+        return [c for c in cand if c <= 2 * h + 1]
+
     def n_split(self, bp):
-        if self.wg_transposed:
-            return P.pick_split(self.n_tiles_t, (self.geom["t_src"] + 2 * self.geom["pad"]) * (bp // 32))
-        return P.pick_split(self.n_tiles, self.geom["t_dst"] * (bp // 32))
+        return self._split_tuned.get(bp, self._split_heuristic(bp))
 
     def slab_floats(self, bp):
-        if self.wg_transposed:
-            return self.n_split(bp) * self.n_tiles_t * self.bwd.g.mt * 16 * 64
-        return self.n_split(bp) * self.n_tiles * self.wg.mt * 16 * 64
+        """Slab size for the largest split the autotuner may pick."""
+        per = self.n_tiles_t * self.bwd.g.mt * 16 * 64 if self.wg_transposed else self.n_tiles * self.wg.mt * 16 * 64
+        return max(self.split_candidates(bp)) * per
+
+    def autotune_split(self, dy, x, dw, bp, slab):
+        if bp in self._split_tuned or not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+            return
+        scratch = torch.empty_like(dw)
+        best = None
+        torch.cuda.synchronize()                 # nothing else on the GPU while the candidates are timed
+        for c in self.split_candidates(bp):
+            self._split_tuned[bp] = c
+
+            def once():
+                self.wgrad_gemm(dy, x, bp, slab)
+                r = self.reduce_desc(slab, scratch, bp, False)
+                _lib.check(_lib.load().hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce")
+            t = self.fwd._time(once)
+            if best is None or t < best[0]:
+                best = (t, c)
+        self._split_tuned[bp] = best[1]
 
     def backward_weight(self, dy, x, dw, bp, slab, accumulate=False):
+        self.autotune_split(dy, x, dw, bp, slab)
         self.wgrad_gemm(dy, x, bp, slab)
         r = self.reduce_desc(slab, dw, bp, accumulate)
         _lib.check(_lib.load().hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce")

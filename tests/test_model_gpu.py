@@ -126,10 +126,13 @@ def test_two_trainer_steps_vs_reference(dev, tag):
         idx = g["upd|" + name + "|idx"]
         delta = v[idx].astype(np.float64) - seeded[name].reshape(-1).numpy()[idx].astype(np.float64)
         ref = g["upd|" + name + "|delta"]
-        # the first Adam steps move every touched weight by ~lr; 2% of lr is far below one step.  (Not tighter: the
-        # encoder's first bias gradients are ~4e-8, a cancelling sum over (t, batch) of terms 1000x larger and only a
-        # few times Adam's eps, so d(update)/d(grad) is ~4e6*lr there and fp32 summation order alone moves it by 1%.)
-        assert np.abs(delta - ref).max() < 2e-2 * cfg["lr"], name
+        # The first two Adam steps move a weight by ~2*lr whenever |grad| >> eps (the update is sign-like): there 2% of lr
+        # is far below one step.  Where the reference moved it by less than 1.9*lr the gradient is only a few times
+        # Adam's eps (1e-8) -- cancelling sums over (t, batch) of terms 1000x larger, e.g. the encoder's first biases at
+        # ~4e-8 -- so d(update)/d(grad) is ~4e6*lr and fp32 summation order alone moves the update by several percent:
+        # those elements get 10% of lr.  (The gradients themselves are checked to 1e-4 in the tests above.)
+        tol = np.where(np.abs(ref) >= 1.9 * cfg["lr"], 2e-2, 1e-1) * cfg["lr"]
+        assert (np.abs(delta - ref) < tol).all(), name
     assert abs(tr.gen_opt.param_groups[0]["lr"] - meta["lr_after_2"]) < 1e-12
     # attributes the reference's write_loss reflects on
     from hm_vae_amd.utils_common import loss_members
