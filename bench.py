@@ -206,6 +206,9 @@ def main():
     ap.add_argument("--no-fk", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph (1) or launch eagerly (0)")
+    ap.add_argument("--sync-losses", type=int, default=0,
+                    help="1: block on every step's loss read-back (like the reference's .item() calls); 0: the read-back "
+                         "lags one step (pinned buffer + event), so the host queues step n+1 while step n runs")
     args = ap.parse_args()
 
     from hm_vae_amd import ddp, _lib
@@ -237,8 +240,9 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    lag = bool(args.graph) and not args.sync_losses
     for _ in range(args.steps):
-        losses = step.run()
+        losses = step.run(lag=lag)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -258,8 +262,9 @@ def main():
                                   "iteration_interval)" % (B, args.phase) if args.phase == 2 else
                       "len64_no_aug_hm_vae.yaml, batch %d per GPU, phase 1" % B,
                       "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world,
-                      "launch": "hipGraph replay" if args.graph else "eager"},
-           "loss_total": float(losses[0])}
+                      "launch": "hipGraph replay" if args.graph else "eager",
+                      "loss_readback": "every step, lagging one step (non-blocking)" if lag else "every step, blocking"},
+           "loss_total": float(step.last_losses()[0]) if lag else float(losses[0])}
 
     if rank == 0 and not args.no_kernel_timing:
         # instrumented extra steps (eager, same workload): per-launch HIP events around every MFMA kernel

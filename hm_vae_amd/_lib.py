@@ -64,7 +64,8 @@ class PackOp(C.Structure):
     _fields_ = [("dense", _ptr), ("packed", _ptr), ("g_nc4", _ptr), ("g_woff", _ptr), ("g_choff", _ptr), ("chan_id", _ptr),
                 ("row_id", _ptr), ("g_okoff", _ptr), ("pair_ok", _ptr), ("n_groups", _i32), ("max_nc4", _i32), ("mt", _i32),
                 ("kt", _i32), ("row_stride", _i32), ("chan_stride", _i32), ("tap_stride", _i32), ("block_start", _i32),
-                ("fold_taps", _ptr), ("fold_mod", _i32), ("fold_swap", _i32), ("fold_tsrc", _i32), ("fold_kt", _i32)]
+                ("cb", _i32), ("fold_taps", _ptr), ("fold_coef", _ptr), ("child_tab", _ptr), ("fold_nf", _i32),
+                ("fold_kt", _i32), ("child_side", _i32), ("fold_pad", _i32)]
 
 
 class RowsumOp(C.Structure):

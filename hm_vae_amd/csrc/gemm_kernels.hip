@@ -526,25 +526,24 @@ extern "C" int hmvae_pack_weights(const float* dense, float* packed, const int32
 
 
 // ---- every pack of the model in one launch (23 launches of 4-15 us each were mostly launch floor) ----
-// One workgroup packs PACK_CB consecutive 4-channel steps of one group: with 16-row groups that is 256 (row, channel)
-// pairs, one per thread, and a quarter of the workgroups (their life is a chain of dependent table reads, so fewer and
-// fuller ones finish sooner).
-constexpr int PACK_CB = 4;
+// One workgroup packs `cb` consecutive 4-channel steps of one group (4 for plain ops: with 16-row groups that is 256
+// (row, channel) pairs, one per thread; their life is a chain of dependent table reads, so fewer and fuller
+// workgroups finish sooner).  Composite ops (hmvae.h: virtual taps, merged channels) stage the real taps of every pair
+// once -- summed over the dense pairs merged into it -- and build all virtual taps from that.
 __global__ __launch_bounds__(256) void pack_multi_kernel(const hmvae_pack_op* __restrict__ ops, int n_ops) {
-    extern __shared__ float img[];                    // [PACK_CB][kt][mt][64]
+    extern __shared__ float img[];                    // [cb][kt][mt][64]
     int oi = 0;
     for (int i = 1; i < n_ops; ++i)
         if ((int)blockIdx.x >= ops[i].block_start) oi = i;          // uniform scan over <= a few dozen entries
     const hmvae_pack_op o = ops[oi];
     const int local = blockIdx.x - o.block_start;
-    const int cblocks = (o.max_nc4 + PACK_CB - 1) / PACK_CB;
-    const int gb = local / cblocks;                                 // group (folded op: group of the unfolded matrix)
-    const int c40 = (local - gb * cblocks) * PACK_CB;
-    const int fmod = o.fold_taps ? o.fold_mod : 1;
-    const int g = gb * fmod;                                        // folded: groups g .. g+fmod-1 are (rows, a = 0..fmod-1)
+    const int cb = o.cb;
+    const int cblocks = (o.max_nc4 + cb - 1) / cb;
+    const int g = local / cblocks;
+    const int c40 = (local - g * cblocks) * cb;
     const int nc4 = o.g_nc4[g];
     if (c40 >= nc4) return;
-    const int ncb = nc4 - c40 < PACK_CB ? nc4 - c40 : PACK_CB;     // steps of this block
+    const int ncb = nc4 - c40 < cb ? nc4 - c40 : cb;               // steps of this block
     const int mt = o.mt, kt = o.kt;
     const int rows = mt * 16;
     const int ppc = rows * 4;                                       // pairs per step
@@ -573,55 +572,55 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const hmvae_pack_op* __
             float* dsti = img + st * step_floats + (r >> 4) * 64 + kk * 16 + (r & 15);
             for (int tap = 0; tap < kt; ++tap) dsti[tap * mt * 64] = ok ? src[(size_t)tap * o.tap_stride] : 0.f;
         }
-        __syncthreads();
-        float* out = o.packed + o.g_woff[g] + (size_t)c40 * step_floats;     // the steps of a group are contiguous
-        const int n = ncb * step_floats;
-        for (int i = tid; i < n; i += 256) out[i] = img[i];
-        return;
-    }
-    // Effective weights of a folded convolution (hmvae.h).  The fmod groups (rows, a) of one unfolded group share rows,
-    // channel list and mask: stage the real taps of the block's (row, channel) pairs once (private to the owning
-    // thread), then build and store the fragments of every a from them.
-    const int kr = o.fold_kt;                              // taps of the dense tensor
-    float* stage = img + PACK_CB * step_floats;            // [step][pair][kr]
-    int* ftab = (int*)(stage + PACK_CB * ppc * kr);        // the op's fold table
-    for (int i = tid; i < (o.fold_swap ? kt : o.fold_mod) * o.fold_tsrc * 4; i += 256) ftab[i] = o.fold_taps[i];
-    for (int pi = tid; pi < ncb * ppc; pi += 256) {
-        const int st = pi / ppc, pair = pi - st * ppc, c4 = c40 + st;
-        int r, kk;
-        pair_rk(pair, r, kk);
-        const int rid = o.row_id[g * rows + r];            // = real * fmod + 0
-        const int cid = o.chan_id[o.g_choff[g] + c4 * 4 + kk];
-        const bool ok = rid >= 0 && cid >= 0 && o.pair_ok[o.g_okoff[g] + r * (nc4 * 4) + c4 * 4 + kk];
-        const float* src = o.dense + (ok ? (size_t)(rid / fmod) * o.row_stride + (size_t)cid * o.chan_stride : 0);
-        float* mine = stage + pi * kr;
-        for (int k = 0; k < kr; ++k) mine[k] = ok ? src[(size_t)k * o.tap_stride] : 0.f;
-    }
-    for (int a = 0; a < fmod; ++a) {
-        __syncthreads();                                   // table loaded / previous image stored
-        for (int pi = tid; pi < ncb * ppc; pi += 256) {
-            const int st = pi / ppc, pair = pi - st * ppc;
-            int r, kk;
-            pair_rk(pair, r, kk);
-            float* dsti = img + st * step_floats + (r >> 4) * 64 + kk * 16 + (r & 15);
-            const float* mine = stage + pi * kr;
-            const int* tp = ftab + (o.fold_swap ? a : a * o.fold_tsrc) * 4;
-            const int tstep = (o.fold_swap ? o.fold_tsrc : 1) * 4;
-            for (int bq = 0; bq < kt; ++bq, tp += tstep) {
-                float v = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int k = tp[i];
-                    if (k >= 0) v += mine[k];              // masked pairs staged zeros
-                }
-                dsti[bq * mt * 64] = v;
-            }
+    } else {
+        const int kr = o.fold_kt;                              // taps of the dense tensor
+        const int nf = o.fold_nf;
+        float* stage = img + cb * step_floats;                 // [step][pair][kr], private to the owning thread
+        int* ftaps = (int*)(stage + cb * ppc * kr);            // [kt][nf]
+        float* fcoef = (float*)(ftaps + kt * nf);
+        for (int i = tid; i < kt * nf; i += 256) {
+            ftaps[i] = o.fold_taps[i];
+            fcoef[i] = o.fold_coef[i];
         }
         __syncthreads();
-        float* out = o.packed + o.g_woff[g + a] + (size_t)c40 * step_floats;
-        const int n = ncb * step_floats;
-        for (int i = tid; i < n; i += 256) out[i] = img[i];
+        for (int pi = tid; pi < ncb * ppc; pi += 256) {
+            const int st = pi / ppc, pair = pi - st * ppc, c4 = c40 + st;
+            int r, kk;
+            pair_rk(pair, r, kk);
+            const int rid = o.row_id[g * rows + r];
+            const int cid = o.chan_id[o.g_choff[g] + c4 * 4 + kk];
+            const unsigned bits = (rid >= 0 && cid >= 0) ? o.pair_ok[o.g_okoff[g] + r * (nc4 * 4) + c4 * 4 + kk] : 0u;
+            float* dsti = img + st * step_floats + (r >> 4) * 64 + kk * 16 + (r & 15);
+            if (!bits) {
+                for (int vt = 0; vt < kt; ++vt) dsti[vt * mt * 64] = 0.f;
+                continue;
+            }
+            float* mine = stage + pi * kr;
+            for (int k = 0; k < kr; ++k) mine[k] = 0.f;
+            for (int ci = 0; ci < 4; ++ci) {                   // dense (row, channel) pairs merged into this one
+                if (!((bits >> ci) & 1u)) continue;
+                int dr = rid, dc = cid;
+                if (o.child_tab) {
+                    if (o.child_side) dr = o.child_tab[rid * 4 + ci];
+                    else dc = o.child_tab[cid * 4 + ci];
+                }
+                const float* src = o.dense + (size_t)dr * o.row_stride + (size_t)dc * o.chan_stride;
+                for (int k = 0; k < kr; ++k) mine[k] += src[(size_t)k * o.tap_stride];
+            }
+            for (int vt = 0; vt < kt; ++vt) {
+                float v = 0.f;
+                for (int j = 0; j < nf; ++j) {
+                    const int k = ftaps[vt * nf + j];
+                    if (k >= 0) v += fcoef[vt * nf + j] * mine[k];
+                }
+                dsti[vt * mt * 64] = v;
+            }
+        }
     }
+    __syncthreads();
+    float* out = o.packed + o.g_woff[g] + (size_t)c40 * step_floats;     // the steps of a group are contiguous
+    const int n = ncb * step_floats;
+    for (int i = tid; i < n; i += 256) out[i] = img[i];
 }
 
 extern "C" int hmvae_pack_weights_multi(const hmvae_pack_op* ops_dev, int32_t n_ops, int32_t total_blocks,

@@ -103,8 +103,17 @@ class VaeEngine:
             cmap = None
             if i == L - 2:      # output lands in the per-edge concat buffer (seq_two_hier_sa_vae.py:280-288)
                 cmap = [(c // self.cD) * (self.cD + self.cH) + (c % self.cD) for c in range(p.dec_cout[i])]
+            # Upsample + Unpool are folded into the convolution's forward and backward-data GEMMs (ops.conv_gemm): they
+            # read / write the coarse tensor directly; the unpooled, upsampled tensor U is only built for the weight
+            # gradient, on its side stream
+            usrc = np.zeros(p.edge_num[lvl], dtype=np.int64)
+            for ci, grp in enumerate(p.pooling[lvl]):
+                for j in grp:
+                    usrc[j] = ci
+            fuse = ops.FOLD and bool(p.dec_up[i])
             self.dec_conv.append(ops.conv_gemm(device, p.neigh[lvl], p.dec_cin[i], p.dec_cout[i], p.K, 1, p.pad, p.pad_mode,
-                                               t_conv, need_dx=True, out_chan_map=cmap))
+                                               t_conv, need_dx=True, out_chan_map=cmap, upsample=fuse,
+                                               unpool_src=usrc if fuse else None))
         kd = p.edge_num[L]
         self.dec_lin[0] = ops.linear_gemm(device, p.dec_feat[0], p.lat_dim[L - 1], kd, p.lat_dim[L - 1], p.dec_feat[0])
         t_cat = p.dec_ts[L - 1]
@@ -351,9 +360,13 @@ class VaeEngine:
         self.dec_lin[L - 1].forward(w["Z0"], w["D%d" % (L - 2)], bp, bias=P["dec.latent_dec_layers.%d.bias" % (L - 1)])
         src = w["H0"]
         for i in range(L):
-            self.dec_unpool[i].forward(src, w["U%d" % i], p.dec_ts[i], bp)
             bias = P[dconv[i] + ".bias"] if p.dec_bias[i] else None
-            self.dec_conv[i].forward(w["U%d" % i], w["D%d" % i], bp, bias=bias, flags=_lib.FLAG_LEAKY if i < L - 1 else 0)
+            if self.dec_conv[i].fused_front:
+                x = src
+            else:
+                self.dec_unpool[i].forward(src, w["U%d" % i], p.dec_ts[i], bp)
+                x = w["U%d" % i]
+            self.dec_conv[i].forward(x, w["D%d" % i], bp, bias=bias, flags=_lib.FLAG_LEAKY if i < L - 1 else 0)
             src = w["D%d" % i]
 
     # ------------------------------------------------------------------------------------------
@@ -436,13 +449,16 @@ class VaeEngine:
             for s in self._side:
                 torch.cuda.current_stream().wait_stream(s)
 
-    def _wgrad(self, op, dy, x, name, bp, w, bias=None):
-        """bias: optional (src, grad_name, rows_key, base, n_out, rows_per_out, row_step) for the row-sum kernel."""
+    def _wgrad(self, op, dy, x, name, bp, w, bias=None, before=None):
+        """bias: optional (src, grad_name, rows_key, base, n_out, rows_per_out, row_step) for the row-sum kernel.
+        before: launches that produce `x`, issued on the same side stream first."""
         slab = w["slabs"][id(op)]
         if not MULTI_REDUCE:
             # default: GEMM + reduction + bias sums all on the side stream, overlapped with the data-gradient chain
             ctx = self._fork() or contextlib.nullcontext()
             with ctx:
+                if before is not None:
+                    before()
                 op.backward_weight(dy, x, self.grad_view(name), bp, slab)
                 if bias is not None:
                     src, gname, key, base, n_out, rows_per, step = bias
@@ -454,6 +470,8 @@ class VaeEngine:
             self._pending_rs.append((src, self.grad_view(gname), self._rows(key, base, len(base)), n_out, rows_per, step))
         ctx = self._fork() or contextlib.nullcontext()
         with ctx:
+            if before is not None:
+                before()
             op.wgrad_gemm(dy, x, bp, slab)
 
     def _backward(self, w, phase2, eps, B, bp):
@@ -475,10 +493,16 @@ class VaeEngine:
             if p.dec_bias[i]:
                 base = (np.arange(p.dec_cout[i]) * t_conv).astype(np.int32)
                 bias = (dy, dconv[i] + ".bias", ("dconvb", i), base, p.dec_cout[i], t_conv, 1)
-            self._wgrad(conv, dy, w["U%d" % i], dconv[i] + ".weight", bp, w, bias)
-            conv.backward_data(dy, w["dU%d" % i], bp)
             dst = w["dH0"] if i == 0 else w["dD%d" % (i - 1)]
-            self.dec_unpool[i].backward(w["dU%d" % i], dst, p.dec_ts[i], bp)
+            if conv.fused_front:
+                src = w["H0"] if i == 0 else w["D%d" % (i - 1)]
+                self._wgrad(conv, dy, w["U%d" % i], dconv[i] + ".weight", bp, w, bias,
+                            before=lambda i=i, src=src: self.dec_unpool[i].forward(src, w["U%d" % i], p.dec_ts[i], bp))
+                conv.backward_data(dy, dst, bp)
+            else:
+                self._wgrad(conv, dy, w["U%d" % i], dconv[i] + ".weight", bp, w, bias)
+                conv.backward_data(dy, w["dU%d" % i], bp)
+                self.dec_unpool[i].backward(w["dU%d" % i], dst, p.dec_ts[i], bp)
         # latent decode layers
         t_cat = p.dec_ts[L - 1]
         lin = self.dec_lin[L - 1]

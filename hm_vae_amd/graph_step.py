@@ -21,6 +21,7 @@ class GraphedStep:
         self.rmat = data[1].to(device=dev, dtype=torch.float32).contiguous().clone()
         self.data = (self.r6, self.rmat) + tuple(data[2:])
         self.graphs = None
+        self._pinned = None
         self.phase2 = None
         self.warmup = warmup
 
@@ -74,8 +75,13 @@ class GraphedStep:
             self.tr.gen_opt.resync_device_steps()
         self.graphs = (g1, g2)
 
-    def run(self):
-        """One training step; returns the nine loss floats like Trainer.gen_update."""
+    def run(self, lag=False):
+        """One training step; returns the nine loss floats like Trainer.gen_update.
+
+        lag=True: the read-back does not stall the GPU -- the losses are copied to pinned host memory asynchronously and
+        the call returns the PREVIOUS step's values (the first call returns this step's), so the host is already
+        queueing step n+1 while step n runs (a blocking read-back leaves the GPU idle for the ~80 us it takes the host
+        to wake up and launch the next graph)."""
         if not self.use_graph:
             out = self.tr.gen_update(self.data, self.cfg, self.it, False)
             self.it += 1
@@ -93,5 +99,23 @@ class GraphedStep:
             self.tr.gen_scheduler.step()
             opt.sync_lr()
         self.it += 1
-        ls = self.losses.tolist()           # the step's only host synchronisation
+        if not lag:
+            ls = self.losses.tolist()       # the step's only host synchronisation
+            return (ls[0], ls[1], ls[2], ls[3], ls[4], 0.0, 0.0, 0.0, 0.0)
+        if self._pinned is None:
+            self._pinned = [torch.empty(8, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._events = [torch.cuda.Event(), torch.cuda.Event()]
+            self._n_lag = 0
+        k = self._n_lag & 1
+        self._pinned[k].copy_(self.losses, non_blocking=True)
+        self._events[k].record()
+        self._n_lag += 1
+        j = k if self._n_lag == 1 else 1 - k    # previous step's slot (this step's on the very first call)
+        self._events[j].synchronize()
+        ls = self._pinned[j].tolist()
+        return (ls[0], ls[1], ls[2], ls[3], ls[4], 0.0, 0.0, 0.0, 0.0)
+
+    def last_losses(self):
+        """Blocking read of the most recent step's losses (after a run(lag=True) loop)."""
+        ls = self.losses.tolist()
         return (ls[0], ls[1], ls[2], ls[3], ls[4], 0.0, 0.0, 0.0, 0.0)

@@ -65,8 +65,16 @@ class _Side:
                  fold=None):
         self.g = groups
         self.device = device
-        # fold = (fold_taps, fold_mod, fold_swap, t_src): the packed matrix is the tap-folded effective one (hmvae.h)
-        self.fold = None if fold is None else (_dev(fold[0], device), int(fold[1]), int(fold[2]), int(fold[3]), int(fold[4]))
+        # fold = dict(taps [kt][nf], coefs [kt][nf], kt_real, child_tab [n][4] or None, child_side): the packed matrix is a
+        # composite one (virtual taps, merged channels; hmvae.h, hmvae_pack_op)
+        self.fold = None
+        if fold is not None:
+            self.fold = dict(taps=_dev(np.ascontiguousarray(fold["taps"], dtype=np.int32).reshape(-1), device),
+                             coefs=torch.as_tensor(np.ascontiguousarray(fold["coefs"], dtype=np.float32).reshape(-1)).to(device),
+                             nf=int(fold["taps"].shape[1]), kt_real=int(fold["kt_real"]),
+                             child_tab=None if fold.get("child_tab") is None else
+                             _dev(np.ascontiguousarray(fold["child_tab"], dtype=np.int32).reshape(-1), device),
+                             child_side=int(fold.get("child_side", 0)))
         self.row_id = _dev(groups.row_id, device)
         self.chan_id = _dev(groups.chan_id, device)
         self.g_nc4 = _dev(groups.g_nc4, device)
@@ -112,19 +120,25 @@ class _Side:
         return _lib.PackOp(_lib.ptr(dense), _lib.ptr(self.wp), _lib.ptr(self.g_nc4), _lib.ptr(self.g_woff),
                            _lib.ptr(self.g_choff), _lib.ptr(self.chan_id), _lib.ptr(self.row_id), _lib.ptr(self.g_okoff),
                            _lib.ptr(self.pair_ok), g.n_groups, int(g.g_nc4.max()), g.mt, g.kt, rs, cs, ts, int(block_start),
-                           None if f is None else _lib.ptr(f[0]), 1 if f is None else f[1], 0 if f is None else f[2],
-                           1 if f is None else f[3], 0 if f is None else f[4])
+                           self.pack_cb(), None if f is None else _lib.ptr(f["taps"]),
+                           None if f is None else _lib.ptr(f["coefs"]),
+                           None if f is None or f["child_tab"] is None else _lib.ptr(f["child_tab"]),
+                           1 if f is None else f["nf"], 0 if f is None else f["kt_real"],
+                           0 if f is None else f["child_side"], 0)
+
+    def pack_cb(self):
+        """4-channel steps per pack workgroup: 4, fewer when the image of a step is large (many virtual taps)."""
+        return int(max(1, min(4, 8192 // (self.g.kt * self.g.mt * 64))))
 
     def pack_lds_floats(self):
-        g = self.g
-        n = 4 * g.kt * g.mt * 64
+        g, cb = self.g, self.pack_cb()
+        n = cb * g.kt * g.mt * 64
         if self.fold is not None:
-            n += 4 * g.mt * 64 * (self.fold[4] + 1) + int(self.fold[0].numel())
+            n += cb * g.mt * 64 * self.fold["kt_real"] + 2 * g.kt * self.fold["nf"]
         return n
 
     def pack_blocks(self):
-        n = self.g.n_groups if self.fold is None else self.g.n_groups // self.fold[1]
-        return n * (-(-int(self.g.g_nc4.max()) // 4))
+        return self.g.n_groups * (-(-int(self.g.g_nc4.max()) // self.pack_cb()))
 
     def items_for(self, np_):
         if np_ not in self._items:
@@ -320,7 +334,7 @@ class MaskedGemm:
     """
 
     def __init__(self, device, w_shape, rows_f, chans_f, rows_b, chans_b, pairs_f, pairs_b, x_base, y_base, x_ts, y_ts,
-                 conv_geom=None, bias_rows=None, fold_t=None):
+                 conv_geom=None, bias_rows=None, composite=None):
         n_rows, n_chan, kt = w_shape
         self.w_shape = tuple(int(v) for v in w_shape)
         self.kt = int(kt)
@@ -329,30 +343,45 @@ class MaskedGemm:
         y_base = np.asarray(y_base, dtype=np.int64)
         gf = P.make_groups(rows_f, chans_f, kt)
         gb = P.make_groups(rows_b, chans_b, kt) if rows_b is not None else None
-        fold_taps = P.fold_table(pairs_f, fold_t[0]) if fold_t is not None else None
-        self.folded = fold_taps is not None
+        comp = composite
+        self.folded = comp is not None
         self.bwd = None
-        if not self.folded:
+        if comp is None:
             self.fwd = _Side(device, gf, pairs_f, x_base, y_base, bias_rows, x_ts, y_ts, (n_chan * kt, kt, 1))
             if rows_b is not None:
                 # transposed: "rows" are forward channels, "channels" are forward rows
                 self.bwd = _Side(device, gb, pairs_b, y_base, x_base, None, y_ts, x_ts, (kt, n_chan * kt, 1))
         else:
-            # Tap folding (hmvae.h, hmvae_pack_op): per output position p the layer is a dense map over the t_src source
-            # positions with effective weights Weff[p][q].  As a MaskedGemm: one "position", effective rows (row, p),
-            # t_src "taps" (q) forward;  effective rows (chan, q), t_dst "taps" (p) for the transposed side.
-            t_src, t_dst = int(fold_t[0]), int(fold_t[1])
-            assert t_dst == len(pairs_f)
-            br = np.arange(n_rows, dtype=np.int64) if bias_rows is None else np.asarray(bias_rows, dtype=np.int64)
-            gfe = P.fold_groups(gf, t_dst, t_src)
-            ydst = (y_base[:, None] + np.arange(t_dst)[None, :] * y_ts).reshape(-1)
-            self.fwd = _Side(device, gfe, [[(q, q) for q in range(t_src)]], x_base, ydst, np.repeat(br, t_dst), x_ts, y_ts,
-                             (n_chan * kt, kt, 1), fold=(fold_taps, t_dst, 0, t_src, kt))
+            # Composite relation (planner.compose_conv / merge_channels; hmvae.h, hmvae_pack_op): the gather sides read
+            # the SOURCE tensor of the composite (e.g. the coarse tensor in front of Upsample + Unpool) through virtual
+            # taps; the weight gradient below keeps the plain relation on `x` (the conv's own input).
+            pe, n_vt = comp["pairs_eff"], int(comp["taps"].shape[0])
+            cmap = comp.get("cmap")                       # fine input channel -> source channel, or None
+            src_base = np.asarray(comp["src_base"], dtype=np.int64)
+            src_ts = int(comp.get("src_ts", x_ts))
+            fold = dict(taps=comp["taps"], coefs=comp["coefs"], kt_real=kt)
+            if cmap is None:
+                gfe = P.make_groups(rows_f, chans_f, n_vt)
+                ffold = dict(fold)
+            else:
+                rf, cf, bits, children = P.merge_channels(rows_f, chans_f, cmap)
+                gfe = P.make_groups(rf, cf, n_vt, pair_bits=bits)
+                ctab = -np.ones((len(src_base), 4), dtype=np.int32)
+                for cc, fl in children.items():
+                    assert len(fl) <= 4
+                    ctab[cc, :len(fl)] = fl
+                ffold = dict(fold, child_tab=ctab, child_side=0)
+            self.fwd = _Side(device, gfe, pe, src_base, y_base, bias_rows, src_ts, y_ts, (n_chan * kt, kt, 1), fold=ffold)
             if rows_b is not None:
-                gbe = P.fold_groups(gb, t_src, t_dst)
-                xdst = (x_base[:, None] + np.arange(t_src)[None, :] * x_ts).reshape(-1)
-                self.bwd = _Side(device, gbe, [[(p, p) for p in range(t_dst)]], y_base, xdst, None, y_ts, x_ts,
-                                 (kt, n_chan * kt, 1), fold=(fold_taps, t_src, 1, t_src, kt))
+                pb = P.transpose_pairs(pe, int(comp["n_src_pos"]))
+                if cmap is None:
+                    gbe = P.make_groups(rows_b, chans_b, n_vt)
+                    bfold = dict(fold)
+                else:
+                    rb, cb_, bits_b, children = P.merge_channels_transposed(rows_b, chans_b, cmap, len(src_base))
+                    gbe = P.make_groups(rb, cb_, n_vt, pair_bits=bits_b)
+                    bfold = dict(fold, child_tab=ctab, child_side=1)
+                self.bwd = _Side(device, gbe, pb, y_base, src_base, None, y_ts, src_ts, (kt, n_chan * kt, 1), fold=bfold)
         # weight gradient tiles: forward grouping, or (masked convs) a grouping keyed by input block whose tiles have
         # several 16-row pieces per activation load and no union waste
         gw = gf
@@ -539,9 +568,18 @@ MaskedGemm._wgrad_gemm_t = _mg_wgrad_gemm_t
 
 
 
-def conv_gemm(device, neigh, cin, cout, kt, stride, pad, pad_mode, t_in, need_dx=True, out_chan_map=None):
+def conv_gemm(device, neigh, cin, cout, kt, stride, pad, pad_mode, t_in, need_dx=True, out_chan_map=None,
+              upsample=False, unpool_src=None):
     """SkeletonConv (skeleton.py:9-105) as a MaskedGemm.  out_chan_map lets the output land in other channel
-    slots (the decoder's per-edge concat, seq_two_hier_sa_vae.py:280-288)."""
+    slots (the decoder's per-edge concat, seq_two_hier_sa_vae.py:280-288).
+
+    upsample / unpool_src describe what the reference puts IN FRONT of a decoder convolution
+    (seq_two_hier_sa_vae.py:233-242): nn.Upsample(x2, linear) and SkeletonUnpool (fine edge e copies coarse edge
+    unpool_src[e]).  Both are linear, so forward and backward-data run as ONE gather-GEMM over the coarse tensor
+    (t_in/2 positions, len(set(unpool_src)) edges): a polyphase filter with ~8 instead of 15 (position, tap) items per
+    output position and the duplicated channels read once through summed weights.  forward()/backward_data() then take
+    / return the COARSE tensor; backward_weight() still takes the conv's own (upsampled, unpooled) input.
+    Convolutions over fewer positions than taps get their taps folded the same way (FOLD)."""
     t_out = (t_in + 2 * pad - kt) // stride + 1
     mode = "reflect" if pad_mode in ("reflect", "reflection") else "zeros"
     if mode == "reflect" and pad >= t_in and pad > 0:
@@ -557,11 +595,35 @@ def conv_gemm(device, neigh, cin, cout, kt, stride, pad, pad_mode, t_in, need_dx
     y_base = oc * t_out
     geom = dict(t_dst=t_out, t_src=t_in, stride=stride, pad=pad,
                 pad_mode=_lib.PAD_REFLECT if mode == "reflect" else _lib.PAD_ZEROS)
-    # short sequences: fewer source positions than taps -> fold the taps into per-position-pair weights
-    fold_t = (t_in, t_out) if (FOLD and t_in < kt and t_in <= 32 and t_out * t_in <= 254) else None
+    composite = None
+    want = FOLD and ((upsample or unpool_src is not None) or t_in < kt)
+    if want:
+        t_src = t_in // 2 if upsample else t_in
+        comp = P.compose_conv(pairs_f, P.upsample_rows(t_src) if upsample else None)
+        if comp is not None:
+            pe, taps, coefs = comp
+            cmap = None
+            n_src_ch = cin
+            if unpool_src is not None:
+                n_edges = len(neigh)
+                ch = cin // n_edges
+                usrc = np.asarray(unpool_src, dtype=np.int64)
+                assert len(usrc) == n_edges
+                cmap = (usrc[:, None] * ch + np.arange(ch)[None, :]).reshape(-1)
+                n_src_ch = (int(usrc.max()) + 1) * ch
+                if np.bincount(usrc).max() > 4:
+                    comp = None
+            items_new = sum(len(l) for l in pe)
+            items_old = sum(len(l) for l in pairs_f)
+            if comp is not None and (items_new < 0.9 * items_old or cmap is not None or upsample):
+                composite = dict(pairs_eff=pe, taps=taps, coefs=coefs, cmap=cmap, n_src_pos=t_src,
+                                 src_base=np.arange(n_src_ch, dtype=np.int64) * t_src, src_ts=1)
+    if composite is None and (upsample or unpool_src is not None):
+        raise _lib.HmvaeError("upsample/unpool in front of this convolution cannot be folded (HMVAE_FOLD=0 or limits)")
     op = MaskedGemm(device, (cout, cin, kt), rows_f, chans_f, rows_b, chans_b, pairs_f, pairs_b, x_base, y_base, 1, 1,
-                    conv_geom=geom, fold_t=fold_t)
+                    conv_geom=geom, composite=composite)
     op.t_in, op.t_out = t_in, t_out
+    op.fused_front = bool(upsample or unpool_src is not None)
     return op
 
 

@@ -14,10 +14,12 @@ import numpy as np
 class GroupSet:
     """Row groups + channel lists for one masked dense matrix W[row, chan, tap]."""
 
-    def __init__(self, mt, groups, kt, row_chans=None):
+    def __init__(self, mt, groups, kt, row_chans=None, pair_bits=None):
         """groups: [(rows, chans)]; row_chans: dense row id -> set of channels that row may read (its mask).
         When rows of several blocks share a group, the union list holds channels that are masked out for some
-        rows: pair_ok marks the (row, channel) pairs that are really in the mask."""
+        rows: pair_ok marks the (row, channel) pairs that are really in the mask.  pair_bits(row, chan) -> uint8
+        replaces the 0/1 entry by a bit mask over the dense (row, channel) pairs merged into this pair (composite
+        relations, see compose_conv)."""
         self.mt = int(mt)
         self.kt = int(kt)
         self.n_groups = len(groups)
@@ -43,6 +45,9 @@ class GroupSet:
             for ri, r in enumerate(rows):
                 if row_chans is None:
                     ok[ri, :nch] = 1
+                elif pair_bits is not None:
+                    allowed = row_chans[r]
+                    ok[ri, :nch] = [pair_bits(r, c) if c in allowed else 0 for c in chans]
                 else:
                     allowed = row_chans[r]
                     ok[ri, :nch] = [1 if c in allowed else 0 for c in chans]
@@ -65,7 +70,7 @@ class GroupSet:
 
     def useful(self):
         """(row, chan) pairs that are real work."""
-        return int(self.pair_ok.sum())
+        return int((self.pair_ok != 0).sum())
 
     # wgrad tiling: 64 (channel,tap) columns per tile
     def wgrad_tiles(self):
@@ -101,7 +106,7 @@ def _merge_units(units, cap):
     return units
 
 
-def make_groups(joint_rows, joint_chans, kt, mt_choices=(1,)):
+def make_groups(joint_rows, joint_chans, kt, mt_choices=(1,), pair_bits=None):
     """joint_rows[j]: dense row ids owned by block j; joint_chans[j]: dense channel ids block j reads.
 
     Default: one 16-row tile per group.  Measured on MI355X at B=256 (tools/profile_layers.py with HMVAE_MT=1..4):
@@ -129,7 +134,7 @@ def make_groups(joint_rows, joint_chans, kt, mt_choices=(1,)):
         units = _merge_units(units, cap)
         groups = [(r, sorted(c)) for r, c in units]
         groups.sort(key=lambda g: min(g[0]))
-        gs = GroupSet(mt, groups, kt, row_chans)
+        gs = GroupSet(mt, groups, kt, row_chans, pair_bits)
         score = gs.mfma_cost() * eff[mt]
         if best is None or score < best[0]:
             best = (score, gs)
@@ -465,35 +470,115 @@ def build_stream_schedule(unit_steps, unit_cost, n_workers, min_steps=3):
             np.asarray(fixups, dtype=np.int64).reshape(-1, 3), n_parts)
 
 
-def fold_table(pairs_f, t_src):
-    """fold_taps[(p*t_src + q)*4 + i]: the (<= 4) taps through which output position p reads source position q (-1 pad).
-    None when some (p, q) needs more than 4."""
-    t_dst = len(pairs_f)
-    tab = -np.ones((t_dst * t_src, 4), dtype=np.int32)
-    cnt = np.zeros(t_dst * t_src, dtype=np.int64)
-    for p, lst in enumerate(pairs_f):
-        for q, tap in lst:
-            i = p * t_src + q
-            if cnt[i] >= 4:
-                return None
-            tab[i, cnt[i]] = tap
-            cnt[i] += 1
-    return tab.reshape(-1)
 
 
-def fold_groups(gs, mod, kt_eff):
-    """Groups of the tap-folded matrix: group g*mod + a holds the rows of group g of `gs` at position a (effective row
-    id = row*mod + a), same channel list and mask; kt_eff effective taps."""
-    rows_per = 16 * gs.mt
-    rid = gs.row_id.reshape(gs.n_groups, rows_per)
-    groups, row_chans = [], {}
-    for gi in range(gs.n_groups):
-        rows = [int(r) for r in rid[gi] if r >= 0]
-        nch = int(gs.g_nch[gi])
-        chans = [int(c) for c in gs.chan_id[gs.g_choff[gi]:gs.g_choff[gi] + nch]]
-        ok = gs.pair_ok[gs.g_okoff[gi]:gs.g_okoff[gi] + rows_per * int(gs.g_nc4[gi]) * 4].reshape(rows_per, -1)
-        for a in range(mod):
-            groups.append(([r * mod + a for r in rows], chans))
-            for ri, r in enumerate(rows):
-                row_chans[r * mod + a] = frozenset(c for ci, c in enumerate(chans) if ok[ri, ci])
-    return GroupSet(gs.mt, groups, kt_eff, row_chans)
+# ---------------------------------------------------------------------------------------------
+# composite relations: convolution o [x2 linear upsample] o [SkeletonUnpool], tap folding
+# ---------------------------------------------------------------------------------------------
+def upsample_rows(t_coarse):
+    """nn.Upsample(scale_factor=2, mode='linear', align_corners=False): fine position t -> [(coarse position, weight)]."""
+    out = []
+    for t in range(2 * t_coarse):
+        i = t >> 1
+        if t & 1:
+            a, b, wa, wb = i, min(i + 1, t_coarse - 1), 0.75, 0.25
+        else:
+            a, b, wa, wb = max(i - 1, 0), i, 0.25, 0.75
+        out.append([(a, 1.0)] if a == b else [(a, wa), (b, wb)])
+    return out
+
+
+def compose_conv(pairs_fine, up=None, max_nf=16, max_vt=254):
+    """Fold a temporal convolution (and the x2 linear upsample in front of it) into VIRTUAL TAPS.
+
+    pairs_fine[p] = [(t, k)]: output position p reads (upsampled) position t through tap k.  With `up`
+    (upsample_rows) every t is a weighted pair of source positions, so per output position the layer is a map over few
+    source positions q with effective weights  Weff[p][q] = sum_k c(p,q,k) W[..,k].  Output positions whose (tap,
+    coefficient) lists coincide share a virtual tap.  Returns (pairs_eff, vt_taps, vt_coefs) with
+    pairs_eff[p] = [(q, vt)], vt_taps/vt_coefs [n_vt][nf] (tap -1 = unused), or None when the lists are too long.
+    """
+    pat_id, pats, pairs_eff = {}, [], []
+    for lst in pairs_fine:
+        acc = {}
+        for t, k in lst:
+            for q, c in (up[t] if up is not None else [(t, 1.0)]):
+                d = acc.setdefault(q, {})
+                d[k] = d.get(k, 0.0) + c
+        eff = []
+        for q in sorted(acc):
+            key = tuple(sorted((k, round(c, 9)) for k, c in acc[q].items()))
+            if key not in pat_id:
+                pat_id[key] = len(pats)
+                pats.append(key)
+            eff.append((q, pat_id[key]))
+        pairs_eff.append(eff)
+    nf = max(len(k) for k in pats) if pats else 1
+    if nf > max_nf or len(pats) > max_vt:
+        return None
+    nf = max(4, -(-nf // 4) * 4)
+    taps = -np.ones((len(pats), nf), dtype=np.int32)
+    coefs = np.zeros((len(pats), nf), dtype=np.float32)
+    for i, key in enumerate(pats):
+        for j, (k, c) in enumerate(key):
+            taps[i, j], coefs[i, j] = k, c
+    return pairs_eff, taps, coefs
+
+
+def transpose_pairs(pairs_eff, n_src):
+    """pairs_b[q] = [(p, vt)] for every (q, vt) in pairs_eff[p]."""
+    out = [[] for _ in range(n_src)]
+    for p, lst in enumerate(pairs_eff):
+        for q, vt in lst:
+            out[q].append((p, vt))
+    return out
+
+
+def merge_channels(joint_rows, joint_chans, cmap):
+    """Forward lists with the fine input channels replaced by the coarse channels they are copies of
+    (cmap[fine] = coarse, SkeletonUnpool folded into the weights).  Returns (rows, chans_coarse, pair_bits) where
+    pair_bits(row, coarse) has bit i set when child i of `coarse` (children[coarse][i]) is in the row's mask."""
+    children = {}
+    for f, cc in enumerate(cmap):
+        children.setdefault(int(cc), []).append(f)
+    row_fine = {}
+    for rows, chans in zip(joint_rows, joint_chans):
+        fs = frozenset(chans)
+        for r in rows:
+            row_fine[r] = fs
+    chans_c = [sorted(set(int(cmap[f]) for f in chans)) for chans in joint_chans]
+
+    def bits(r, cc):
+        allowed = row_fine[r]
+        return sum(1 << i for i, f in enumerate(children[cc]) if f in allowed)
+    return joint_rows, chans_c, bits, children
+
+
+def merge_channels_transposed(rows_b, chans_b, cmap, n_coarse):
+    """Transposed lists with the fine channels (the rows of this side) merged into coarse ones: rows = coarse channels of
+    one coarse block, channels = every output row that reads one of their children."""
+    children = {}
+    for f, cc in enumerate(cmap):
+        children.setdefault(int(cc), []).append(f)
+    reads = {}                       # fine channel -> set of output rows reading it
+    for rows, chans in zip(rows_b, chans_b):
+        fs = frozenset(chans)
+        for f in rows:
+            reads[f] = fs
+    # blocks: coarse channels whose children sit in the same fine blocks are grouped like their first child
+    blk_of_fine = {}
+    for bi, rows in enumerate(rows_b):
+        for f in rows:
+            blk_of_fine[f] = bi
+    blocks = {}
+    for cc in range(n_coarse):
+        if cc in children:
+            key = tuple(sorted(set(blk_of_fine[f] for f in children[cc])))
+            blocks.setdefault(key, []).append(cc)
+    rows_c, chans_c = [], []
+    for key in sorted(blocks):
+        rows_c.append(blocks[key])
+        chans_c.append(sorted(set().union(*[reads[f] for cc in blocks[key] for f in children[cc]])))
+
+    def bits(cc, r):
+        return sum(1 << i for i, f in enumerate(children[cc]) if r in reads[f])
+    return rows_c, chans_c, bits, children

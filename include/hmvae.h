@@ -224,20 +224,25 @@ typedef struct {
     const uint8_t* pair_ok;
     int32_t n_groups, max_nc4, mt, kt;
     int32_t row_stride, chan_stride, tap_stride, block_start;
-    /* Tap folding (short sequences).  A convolution over t_src < kt positions reads every source position through up
-     * to 3 taps (reflection), so per output position p it is a dense map over the t_src source positions q with
-     * weights Weff[p][q] = sum of W[.., k] over the taps k that connect them: t_src products instead of kt.  With
-     * fold_taps != NULL the packed matrix is that effective one: row_id holds (row * fold_mod + a), groups g*fold_mod + a
-     * (a = 0..fold_mod-1) are the same 16 rows and channel list at position a, the packed "tap"
-     * index is b, (p, q) = (a, b) (fold_swap 0, forward) or (b, a) (fold_swap 1, the transposed side), and the value
-     * packed is the sum of dense[row, chan, fold_taps[(p*fold_tsrc + q)*4 + i]] over the entries >= 0. */
-    const int32_t* fold_taps;
-    int32_t fold_mod, fold_swap, fold_tsrc, fold_kt;   /* fold_kt: taps of the dense tensor */
+    int32_t cb;              /* 4-channel steps per workgroup (1..4) */
+    /* Composite ops: the packed matrix is  Weff[row, chan, vt] = sum_j fold_coef[vt][j] * sum_i W[row_i, chan_i,
+     * fold_taps[vt][j]]  with `kt` VIRTUAL taps vt over the fold_kt taps of the dense tensor (taps < 0 unused), and the
+     * inner sum over the dense (row, channel) pairs merged into the packed pair: bit i of pair_ok selects child i,
+     * child_tab[id*4 + i], of the packed channel (child_side 0) or of the packed row (child_side 1); without child_tab
+     * the pair is itself (bit 0).  This is how a convolution over few positions (taps folded per position pair), the x2
+     * linear upsample in front of a decoder convolution (a polyphase filter over the coarse positions) and
+     * SkeletonUnpool (copies of a coarse channel read through summed weights) run as plain gather-GEMMs over fewer
+     * (position, tap) items and channels; planner.compose_conv / merge_channels build the tables.  fold_taps == NULL:
+     * plain op, pair_ok is 0/1. */
+    const int32_t* fold_taps;   /* [kt][fold_nf] */
+    const float* fold_coef;     /* [kt][fold_nf] */
+    const int32_t* child_tab;   /* [n][4] or NULL */
+    int32_t fold_nf, fold_kt, child_side, fold_pad;
 } hmvae_pack_op;
 
-/* One workgroup per (group, 4 consecutive 4-channel steps): op i owns the blocks block_start ..
- * block_start + n_groups*ceil(max_nc4/4) (a folded op: n_groups/fold_mod, one block builds all fold_mod positions).  max_lds_floats: the largest per-op LDS need, 4*kt*mt*64 floats, plus
- * 4*mt*64*(fold_kt + 1) + (fold table entries) for a folded op */
+/* One workgroup per (group, cb consecutive 4-channel steps): op i owns the blocks block_start ..
+ * block_start + n_groups*ceil(max_nc4/cb).  max_lds_floats: the largest per-op LDS need, cb*kt*mt*64 floats, plus
+ * cb*mt*64*fold_kt + 2*kt*fold_nf for a composite op */
 int hmvae_pack_weights_multi(const hmvae_pack_op* ops_dev, int32_t n_ops, int32_t total_blocks, int32_t max_lds_floats,
                              hmvae_stream_t stream);
 

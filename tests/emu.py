@@ -15,25 +15,38 @@ def emu_pack(side, dense):
     wp = np.zeros(max(g.packed_size, 1), dtype=np.float32)
     row_id = g.row_id.reshape(g.n_groups, g.mt * 16)
     fold = getattr(side, "fold", None)
-    if fold is not None:
-        taps, mod, swap, tsrc = _np(fold[0]).reshape(-1, 4), fold[1], fold[2], fold[3]
+    if fold is not None:        # composite op (hmvae_pack_op): virtual taps over merged dense pairs
+        nf, kr = fold["nf"], fold["kt_real"]
+        taps, coefs = _np(fold["taps"]).reshape(-1, nf), _np(fold["coefs"]).reshape(-1, nf)
+        ctab = None if fold["child_tab"] is None else _np(fold["child_tab"]).reshape(-1, 4)
     for gi in range(g.n_groups):
         for c4 in range(int(g.g_nc4[gi])):
-            for tap in range(g.kt):
-                for mt in range(g.mt):
-                    for kk in range(4):
-                        cid = g.chan_id[g.g_choff[gi] + c4 * 4 + kk]
-                        for m in range(16):
-                            rid = row_id[gi, mt * 16 + m]
-                            ok = g.pair_ok[g.g_okoff[gi] + (mt * 16 + m) * (int(g.g_nc4[gi]) * 4) + c4 * 4 + kk]
-                            if rid >= 0 and cid >= 0 and ok:
-                                idx = g.g_woff[gi] + ((c4 * g.kt + tap) * g.mt + mt) * 64 + kk * 16 + m
-                                if fold is None:
-                                    wp[idx] = dense[rid * rs + cid * cs + tap * ts]
-                                else:       # tap folding (hmvae_pack_op): sum of the taps connecting (p, q)
-                                    real, a = divmod(int(rid), mod)
-                                    pq = tap * tsrc + a if swap else a * tsrc + tap
-                                    wp[idx] = np.float32(sum(dense[real * rs + cid * cs + k * ts] for k in taps[pq] if k >= 0))
+            for mt in range(g.mt):
+                for kk in range(4):
+                    cid = g.chan_id[g.g_choff[gi] + c4 * 4 + kk]
+                    for m in range(16):
+                        rid = row_id[gi, mt * 16 + m]
+                        bits = int(g.pair_ok[g.g_okoff[gi] + (mt * 16 + m) * (int(g.g_nc4[gi]) * 4) + c4 * 4 + kk])
+                        if rid < 0 or cid < 0 or not bits:
+                            continue
+                        if fold is None:
+                            vals = [dense[rid * rs + cid * cs + tap * ts] for tap in range(g.kt)]
+                        else:
+                            real = np.zeros(kr, dtype=np.float32)
+                            for ci in range(4):
+                                if not (bits >> ci) & 1:
+                                    continue
+                                dr, dc = rid, cid
+                                if ctab is not None:
+                                    if fold["child_side"]:
+                                        dr = ctab[rid, ci]
+                                    else:
+                                        dc = ctab[cid, ci]
+                                real += np.array([dense[dr * rs + dc * cs + k * ts] for k in range(kr)], dtype=np.float32)
+                            vals = [np.float32(sum(coefs[vt, j] * real[taps[vt, j]] for j in range(nf) if taps[vt, j] >= 0))
+                                    for vt in range(g.kt)]
+                        for tap in range(g.kt):
+                            wp[g.g_woff[gi] + ((c4 * g.kt + tap) * g.mt + mt) * 64 + kk * 16 + m] = vals[tap]
     return wp
 
 

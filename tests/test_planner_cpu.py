@@ -81,11 +81,14 @@ def test_conv_tables_reproduce_oracle(case):
     dw = np.zeros((cout, cin, K), dtype=np.float32)
     emu_wgrad(op, to_soa(gy), to_soa(x.detach()), dw)
     assert rel_err(dw, (w.grad * mask).numpy()) < 1e-5
-    assert op.folded == (T < K)
-    # grouping sanity: every masked (row, chan) pair is covered exactly once (per output position when folded)
+    assert op.folded or not (T < K and case["mode"] == "reflect")     # zero padding has nothing to fold
+    assert not (op.folded and T >= K)
+    if op.folded:               # fewer (position, virtual tap) items than (position, tap) ones
+        assert sum(len(l) for l in op.fwd.pairs_host) < T_out * K
+    # grouping sanity: every masked (row, chan) pair is covered exactly once
     g = op.fwd.g
-    cover = np.zeros((cout * (T_out if op.folded else 1), cin), dtype=np.int32)
-    mask_rows = np.repeat(mask[:, :, 0].numpy(), T_out if op.folded else 1, axis=0)
+    cover = np.zeros((cout, cin), dtype=np.int32)
+    mask_rows = mask[:, :, 0].numpy()
     rid = g.row_id.reshape(g.n_groups, -1)
     for gi in range(g.n_groups):
         rows = rid[gi][rid[gi] >= 0]
@@ -94,6 +97,52 @@ def test_conv_tables_reproduce_oracle(case):
         cover[np.ix_(rows, ch)] += 1
     assert (cover[mask_rows > 0] == 1).all()
     assert cover.max() == 1
+
+
+@pytest.mark.parametrize("case", [
+    dict(level=2, ch=2, co=3, K=15, Tc=4),       # dec0-like: 4 coarse positions, no edge is duplicated
+    dict(level=1, ch=2, co=2, K=15, Tc=8),       # dec1-like
+    dict(level=0, ch=1, co=1, K=5, Tc=6),        # finest level: 24 edges from 14
+])
+def test_conv_behind_upsample_unpool_reproduces_oracle(case):
+    """The composite gather-GEMM (Upsample x2 linear + SkeletonUnpool folded into the conv, planner.compose_conv /
+    merge_channels) on the COARSE tensor == conv(upsample(unpool(coarse))) of the oracle, forward and both gradients."""
+    torch.manual_seed(3 + case["level"])
+    edges = topology.edges_from_parents(topology.SMPL24_PARENTS)
+    for _ in range(case["level"]):
+        edges = topology.derive_pooling(edges)[2]
+    pooling = topology.derive_pooling(edges)[1]                  # coarse edge -> its fine edges
+    neigh = topology.find_neighbor(edges, 2)
+    n_f, n_c = len(neigh), len(pooling)
+    src = np.zeros(n_f, dtype=np.int64)
+    for i, grp in enumerate(pooling):
+        for j in grp:
+            src[j] = i
+    ch, K, Tc = case["ch"], case["K"], case["Tc"]
+    cin, cout, T = n_f * ch, n_f * case["co"], 2 * Tc
+    pad, B = (K - 1) // 2, 3
+    mask = O.conv_mask(neigh, cin, cout, K)
+    w = (torch.randn(cout, cin, K) * mask).requires_grad_(True)
+    b = torch.randn(cout, requires_grad=True)
+    xc = torch.randn(B, n_c * ch, Tc, requires_grad=True)
+    idx = torch.as_tensor((src[:, None] * ch + np.arange(ch)[None, :]).reshape(-1))
+    U = F.interpolate(xc[:, idx, :], scale_factor=2, mode="linear", align_corners=False)
+    U.retain_grad()
+    y = O.skel_conv(U, w, mask, b, 1, pad, "reflect")
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    op = ops.conv_gemm("cpu", neigh, cin, cout, K, 1, pad, "reflect", T, need_dx=True, upsample=True, unpool_src=src)
+    assert op.folded and op.fused_front
+    assert op.fwd.g.mfma_cost() * op.fwd.g.kt * 0 + sum(len(l) for l in op.fwd.pairs_host) < T * K
+    ys = np.zeros((cout * T, ops.pad_batch(B)), dtype=np.float32)
+    emu_gather(op.fwd, emu_pack(op.fwd, w.detach().numpy()), to_soa(xc.detach()), ys, bias=b.detach().numpy())
+    assert rel_err(from_soa(ys, B, cout, T).numpy(), y.detach().numpy()) < 1e-5
+    dxs = np.zeros((n_c * ch * Tc, ops.pad_batch(B)), dtype=np.float32)
+    emu_gather(op.bwd, emu_pack(op.bwd, w.detach().numpy()), to_soa(gy), dxs)
+    assert rel_err(from_soa(dxs, B, n_c * ch, Tc).numpy(), xc.grad.numpy()) < 1e-5
+    dw = np.zeros((cout, cin, K), dtype=np.float32)
+    emu_wgrad(op, to_soa(gy), to_soa(U.detach()), dw)              # the weight gradient keeps the conv's own input
+    assert rel_err(dw, (w.grad * mask).numpy()) < 1e-5
 
 
 def test_linear_tables_reproduce_oracle():
