@@ -33,7 +33,7 @@ class Gemm2Desc(C.Structure):
                 ("g_woff", _ptr), ("g_choff", _ptr), ("chan_rows", _ptr), ("dst_rows", _ptr), ("pb_off", _ptr),
                 ("pb_len", _ptr), ("items", _ptr), ("n_groups", _i32), ("mt", _i32), ("kt", _i32), ("n_pos", _i32),
                 ("bp", _i32), ("np", _i32), ("n_pblk", _i32), ("n_units", _i32), ("ksplit", _i32), ("xcd_mode", _i32), ("wpos", _i32), ("max_items", _i32), ("max_nc4", _i32), ("src_ts", _i32),
-                ("dst_ts", _i32), ("flags", _i32), ("slope", _f32), ("debug", _ptr)]
+                ("dst_ts", _i32), ("flags", _i32), ("slope", _f32), ("debug", _ptr), ("bias_idx2", _ptr)]
 
 
 class Conv3Desc(C.Structure):
@@ -44,7 +44,7 @@ class Conv3Desc(C.Structure):
                 ("scratch", _ptr), ("n_groups", _i32), ("kt", _i32), ("bp", _i32), ("n_chunks", _i32), ("ts", _i32),
                 ("win", _i32), ("max_nc4", _i32), ("max_items", _i32), ("un", _i32), ("n_workers", _i32),
                 ("n_fixups", _i32), ("lds_floor", _i32), ("src_ts", _i32), ("dst_ts", _i32), ("flags", _i32),
-                ("slope", _f32)]
+                ("slope", _f32), ("bias_idx2", _ptr)]
 
 
 class WgradDesc(C.Structure):
@@ -57,7 +57,7 @@ class WgradDesc(C.Structure):
 class WreduceDesc(C.Structure):
     _fields_ = [("slab", _ptr), ("dense", _ptr), ("tile_g", _ptr), ("tile_col0", _ptr), ("g_ncols", _ptr),
                 ("g_choff", _ptr), ("chan_id", _ptr), ("row_id", _ptr), ("g_nc4", _ptr), ("g_okoff", _ptr), ("pair_ok", _ptr),
-                ("n_tiles", _i32), ("mt", _i32), ("kt", _i32), ("n_split", _i32), ("row_stride", _i32), ("chan_stride", _i32), ("accumulate", _i32)]
+                ("n_tiles", _i32), ("mt", _i32), ("kt", _i32), ("n_split", _i32), ("row_stride", _i32), ("chan_stride", _i32), ("accumulate", _i32), ("child_tab", _ptr), ("child_scale", _ptr), ("child_side", _i32), ("pad_", _i32)]
 
 
 class PackOp(C.Structure):
@@ -65,7 +65,7 @@ class PackOp(C.Structure):
                 ("row_id", _ptr), ("g_okoff", _ptr), ("pair_ok", _ptr), ("n_groups", _i32), ("max_nc4", _i32), ("mt", _i32),
                 ("kt", _i32), ("row_stride", _i32), ("chan_stride", _i32), ("tap_stride", _i32), ("block_start", _i32),
                 ("cb", _i32), ("fold_taps", _ptr), ("fold_coef", _ptr), ("child_tab", _ptr), ("fold_nf", _i32),
-                ("fold_kt", _i32), ("child_side", _i32), ("fold_pad", _i32)]
+                ("fold_kt", _i32), ("child_side", _i32), ("fold_pad", _i32), ("child_scale", _ptr)]
 
 
 class RowsumOp(C.Structure):
@@ -92,6 +92,7 @@ _SIGS = {
     "hmvae_wgrad_reduce": ([C.POINTER(WreduceDesc), _ptr], _i32),
     "hmvae_pack_weights": ([_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_wgrad_reduce_multi": ([_ptr, _ptr, _i32, _i32, _ptr], _i32),
+    "hmvae_row_sums_scaled": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_row_sums_multi": ([_ptr, _i32, _i32, _ptr], _i32),
     "hmvae_pack_weights_multi": ([_ptr, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_pool_leaky_fwd": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),

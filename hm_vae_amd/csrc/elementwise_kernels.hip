@@ -251,6 +251,33 @@ extern "C" int hmvae_row_sums(const float* src, float* dst, const int32_t* rows,
     return LAUNCH_OK();
 }
 
+__global__ __launch_bounds__(256) void row_sums_scaled_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                               const int* __restrict__ rows, const float* __restrict__ scale,
+                                                               int rows_per_out, int row_step, int n_cols) {
+    __shared__ float sh[4];
+    const int o = blockIdx.x;
+    const int base = rows[o];
+    float s = 0.f;
+    const int nq = n_cols >> 2;
+    for (int k = threadIdx.x >> 6; k < rows_per_out; k += 4) {
+        const f32x4* p = (const f32x4*)(src + (size_t)(base + k * row_step) * n_cols);
+        for (int q = threadIdx.x & 63; q < nq; q += 64) {
+            const f32x4 v = p[q];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    }
+    const float tot = block_sum256(s, sh);
+    if (threadIdx.x == 0) dst[o] = scale[o] * tot;
+}
+
+extern "C" int hmvae_row_sums_scaled(const float* src, float* dst, const int32_t* rows, const float* scale, int32_t n_out,
+                                     int32_t rows_per_out, int32_t row_step, int32_t n_cols, hmvae_stream_t stream) {
+    if (!src || !dst || !rows || !scale || n_out <= 0 || rows_per_out <= 0 || (n_cols & 3)) return HMVAE_ERR_ARG;
+    hipLaunchKernelGGL(row_sums_scaled_kernel, dim3(n_out), dim3(256), 0, (hipStream_t)stream, src, dst, rows, scale,
+                       rows_per_out, row_step, n_cols);
+    return LAUNCH_OK();
+}
+
 __global__ __launch_bounds__(256) void row_sums_multi_kernel(const hmvae_rowsum_op* __restrict__ ops, int n_ops) {
     __shared__ float sh[4];
     int oi = 0;

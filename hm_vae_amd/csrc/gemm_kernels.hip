@@ -432,9 +432,22 @@ __device__ __forceinline__ void wreduce_body(const hmvae_wreduce_desc& d, int bl
             if (rid < 0 || !okp[row * ok_stride]) continue;
             float s = 0.f;
             for (int sp = 0; sp < d.n_split; ++sp) s += sl[sp * split_stride + row * 64];
-            float* o = ocol + (size_t)rid * d.row_stride;
-            if (d.accumulate) s += *o;
-            *o = s;
+            if (d.child_tab == nullptr) {
+                float* o = ocol + (size_t)rid * d.row_stride;
+                if (d.accumulate) s += *o;
+                *o = s;
+            } else {                                   // one computed gradient, several dense (row, channel) owners
+                const unsigned bits = okp[row * ok_stride];
+                if (d.child_scale) s *= d.child_scale[d.child_side ? rid : cid];
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) {
+                    if (!((bits >> ci) & 1u)) continue;
+                    const int dr = d.child_side ? d.child_tab[rid * 4 + ci] : rid;
+                    const int dc = d.child_side ? cid : d.child_tab[cid * 4 + ci];
+                    float* o = d.dense + (size_t)dr * d.row_stride + (size_t)dc * d.chan_stride + tap;
+                    *o = d.accumulate ? *o + s : s;
+                }
+            }
         }
     }
 }
@@ -606,6 +619,10 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const hmvae_pack_op* __
                 }
                 const float* src = o.dense + (size_t)dr * o.row_stride + (size_t)dc * o.chan_stride;
                 for (int k = 0; k < kr; ++k) mine[k] += src[(size_t)k * o.tap_stride];
+            }
+            if (o.child_scale) {                               // e.g. 1/2: the packed row is the MEAN of its children
+                const float sc = o.child_scale[o.child_side ? rid : cid];
+                for (int k = 0; k < kr; ++k) mine[k] *= sc;
             }
             for (int vt = 0; vt < kt; ++vt) {
                 float v = 0.f;

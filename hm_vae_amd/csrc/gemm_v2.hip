@@ -234,7 +234,11 @@ __global__ __launch_bounds__(512) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
                     f32x4 s = {tot[cu][mt][0][r], tot[cu][mt][1][r], tot[cu][mt][2][r], tot[cu][mt][3][r]};
                     if (d.bias) {
                         const int bi = d.bias_idx[g * (MT * 16) + row];
-                        const float bv = bi >= 0 ? d.bias[bi] : 0.f;
+                        float bv = bi >= 0 ? d.bias[bi] : 0.f;
+                        if (d.bias_idx2) {               // row = mean of two dense rows (SkeletonPool folded in)
+                            const int b2 = d.bias_idx2[g * (MT * 16) + row];
+                            if (b2 >= 0) bv = 0.5f * (bv + d.bias[b2]);
+                        }
                         s += (f32x4){bv, bv, bv, bv};
                     }
                     if (d.flags & HMVAE_FLAG_LEAKY) {
@@ -271,7 +275,11 @@ __global__ __launch_bounds__(512) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
             for (int w = 1; w < nw; ++w) s += *(const f32x4*)(redf + w * (MT * 16 * 64) + row * 64 + (cq << 2));
             if (d.bias) {
                 const int bi = d.bias_idx[g * (MT * 16) + row];
-                const float bv = bi >= 0 ? d.bias[bi] : 0.f;
+                float bv = bi >= 0 ? d.bias[bi] : 0.f;
+                if (d.bias_idx2) {
+                    const int b2 = d.bias_idx2[g * (MT * 16) + row];
+                    if (b2 >= 0) bv = 0.5f * (bv + d.bias[b2]);
+                }
                 s += (f32x4){bv, bv, bv, bv};
             }
             if (d.flags & HMVAE_FLAG_LEAKY) {

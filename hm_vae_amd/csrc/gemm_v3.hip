@@ -45,7 +45,11 @@ __device__ __forceinline__ void emit(const hmvae_conv3_desc& d, int g, int row, 
     if (drow < 0) return;
     if (d.bias) {
         const int bi = d.bias_idx[g * 16 + row];
-        const float bv = bi >= 0 ? d.bias[bi] : 0.f;
+        float bv = bi >= 0 ? d.bias[bi] : 0.f;
+        if (d.bias_idx2) {                   // row = mean of two dense rows (SkeletonPool folded in)
+            const int b2 = d.bias_idx2[g * 16 + row];
+            if (b2 >= 0) bv = 0.5f * (bv + d.bias[b2]);
+        }
         s += (f32x4){bv, bv, bv, bv};
     }
     if (d.flags & HMVAE_FLAG_LEAKY) {

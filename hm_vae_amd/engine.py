@@ -84,9 +84,15 @@ class VaeEngine:
         # ---- encoder ops ----
         self.enc_conv, self.enc_pool, self.enc_lin = [], [], []
         for i in range(L):
+            pool = ops.PoolOp(device, p.pooling[i], p.edge_num[i], p.enc_cout[i] // p.edge_num[i])
+            # SkeletonPool + LeakyReLU are folded into the convolution's forward / backward-data GEMMs (ops.conv_gemm):
+            # forward writes the pooled activated tensor A directly; the gradient w.r.t. the conv's own rows (dY) is only
+            # built for the weight gradient, on its side stream
+            fuse = ops.FOLD and pool.covered and all(len(g) <= 2 for g in p.pooling[i])
             self.enc_conv.append(ops.conv_gemm(device, p.neigh[i], p.enc_cin[i], p.enc_cout[i], p.K, p.strides[i], p.pad,
-                                               p.pad_mode, p.tsteps[i], need_dx=(i > 0)))
-            self.enc_pool.append(ops.PoolOp(device, p.pooling[i], p.edge_num[i], p.enc_cout[i] // p.edge_num[i]))
+                                               p.pad_mode, p.tsteps[i], need_dx=(i > 0),
+                                               pool_groups=p.pooling[i] if fuse else None))
+            self.enc_pool.append(pool)
             k = p.edge_num[i + 1]
             self.enc_lin.append(ops.linear_gemm(device, 2 * p.lat_dim[i], p.feat[i], k, p.feat[i], 2 * p.lat_dim[i]))
         # ---- decoder ops ----
@@ -148,6 +154,12 @@ class VaeEngine:
             tot += 2 * op.useful_macs_per_col
         return tot
 
+    def _scales(self, key, scale):
+        k = ("scale", key)
+        if k not in self._bias_rows:
+            self._bias_rows[k] = torch.as_tensor(np.asarray(scale, dtype=np.float32)).to(self.device)
+        return self._bias_rows[k]
+
     def _rows(self, key, base, count):
         k = (key, count)
         if k not in self._bias_rows:
@@ -175,6 +187,7 @@ class VaeEngine:
             w["Y%d" % i], w["dY%d" % i] = buf(p.enc_cout[i] * t), buf(p.enc_cout[i] * t)
             pc = p.ch_base[i + 1] * p.edge_num[i + 1]
             w["A%d" % i], w["dA%d" % i] = buf(pc * t), buf(pc * t)
+            w["dP%d" % i] = buf(pc * t)                   # gradient w.r.t. the pooled pre-activation (fused pool)
             k, d = p.edge_num[i + 1], p.lat_dim[i]
             w["ZD%d" % i], w["dZD%d" % i] = buf(k * 2 * d), buf(k * 2 * d)
             w["Z%d" % i], w["dZ%d" % i] = buf(k * d), buf(k * d)
@@ -346,8 +359,11 @@ class VaeEngine:
         enc_w, enc_b, _ = self.names()
         x = w["X0"]
         for i in range(p.L):
-            self.enc_conv[i].forward(x, w["Y%d" % i], bp, bias=P[enc_b[i]])
-            self.enc_pool[i].forward(w["Y%d" % i], w["A%d" % i], p.tsteps[i + 1], bp)
+            if self.enc_conv[i].fused_pool:
+                self.enc_conv[i].forward(x, w["A%d" % i], bp, bias=P[enc_b[i]], flags=_lib.FLAG_LEAKY)
+            else:
+                self.enc_conv[i].forward(x, w["Y%d" % i], bp, bias=P[enc_b[i]])
+                self.enc_pool[i].forward(w["Y%d" % i], w["A%d" % i], p.tsteps[i + 1], bp)
             x = w["A%d" % i]
         for i in heads:
             self.enc_lin[i].forward(w["A%d" % i], w["ZD%d" % i], bp, bias=P["enc.latent_enc_layers.%d.bias" % i])
@@ -461,11 +477,17 @@ class VaeEngine:
                     before()
                 op.backward_weight(dy, x, self.grad_view(name), bp, slab)
                 if bias is not None:
-                    src, gname, key, base, n_out, rows_per, step = bias
-                    ops.row_sums(src, self.grad_view(gname), self._rows(key, base, len(base)), n_out, rows_per, step, bp)
+                    src, gname, key, base, n_out, rows_per, step = bias[:7]
+                    if len(bias) > 7:       # factor per output: rows averaged by a folded SkeletonPool
+                        ops.row_sums_scaled(src, self.grad_view(gname), self._rows(key, base, len(base)),
+                                            self._scales(key, bias[7]), n_out, rows_per, step, bp)
+                    else:
+                        ops.row_sums(src, self.grad_view(gname), self._rows(key, base, len(base)), n_out, rows_per, step, bp)
             return
         self._pending_red.append((op, slab, self.grad_view(name)))
         if bias is not None:
+            if len(bias) > 7:
+                raise _lib.HmvaeError("HMVAE_MULTI_REDUCE=1 does not support folded pooling (set HMVAE_FOLD=0)")
             src, gname, key, base, n_out, rows_per, step = bias
             self._pending_rs.append((src, self.grad_view(gname), self._rows(key, base, len(base)), n_out, rows_per, step))
         ctx = self._fork() or contextlib.nullcontext()
@@ -541,13 +563,30 @@ class VaeEngine:
                             (w["dZD0"], "enc.latent_enc_layers.0.bias", ("elinb", 0), base, 2 * d0, k0, 2 * d0))
                 lin.backward_data(w["dZD0"], w["dA0"], bp, accumulate=True)
             t = p.tsteps[i + 1]
-            self.enc_pool[i].backward(w["dA%d" % i], w["A%d" % i], w["dY%d" % i], t, bp)
             conv = self.enc_conv[i]
             x = w["X0"] if i == 0 else w["A%d" % (i - 1)]
             base = (np.arange(p.enc_cout[i]) * t).astype(np.int32)
-            self._wgrad(conv, w["dY%d" % i], x, enc_w[i], bp, w, (w["dY%d" % i], enc_b[i], ("econvb", i), base, p.enc_cout[i], t, 1))
-            if i > 0:
-                conv.backward_data(w["dY%d" % i], w["dA%d" % (i - 1)], bp)
+            bias = (w["dY%d" % i], enc_b[i], ("econvb", i), base, p.enc_cout[i], t, 1)
+            if conv.fused_pool:
+                # gradient w.r.t. the pooled pre-activation: feeds the backward-data GEMM and -- the rows a pool group
+                # averages share their gradient -- the deduplicated weight gradient and the bias sums
+                ops.leaky_bwd(w["dA%d" % i], w["A%d" % i], w["dP%d" % i], w["dA%d" % i].numel())
+                if conv.wg_pooled_dz:
+                    rows_p = conv.pool_dst_base[conv.pool_rmap].astype(np.int32)
+                    bias_p = (w["dP%d" % i], enc_b[i], ("econvbp", i), rows_p, p.enc_cout[i], t, 1,
+                              conv.pool_scale[conv.pool_rmap])
+                    self._wgrad(conv, w["dP%d" % i], x, enc_w[i], bp, w, bias_p)
+                else:
+                    self._wgrad(conv, w["dY%d" % i], x, enc_w[i], bp, w, bias,
+                                before=lambda i=i, t=t: self.enc_pool[i].backward(w["dA%d" % i], w["A%d" % i],
+                                                                                  w["dY%d" % i], t, bp))
+                if i > 0:
+                    conv.backward_data(w["dP%d" % i], w["dA%d" % (i - 1)], bp)
+            else:
+                self.enc_pool[i].backward(w["dA%d" % i], w["A%d" % i], w["dY%d" % i], t, bp)
+                self._wgrad(conv, w["dY%d" % i], x, enc_w[i], bp, w, bias)
+                if i > 0:
+                    conv.backward_data(w["dY%d" % i], w["dA%d" % (i - 1)], bp)
         self._join()
         if MULTI_REDUCE:
             if self._multired is None:

@@ -62,7 +62,7 @@ class _Side:
     """One gather-GEMM direction: groups + position pairs + row maps (all on the device)."""
 
     def __init__(self, device, groups, pairs, chan_row_base, row_dst_base, bias_rows, src_ts, dst_ts, dense_strides,
-                 fold=None):
+                 fold=None, bias_rows2=None):
         self.g = groups
         self.device = device
         # fold = dict(taps [kt][nf], coefs [kt][nf], kt_real, child_tab [n][4] or None, child_side): the packed matrix is a
@@ -74,7 +74,9 @@ class _Side:
                              nf=int(fold["taps"].shape[1]), kt_real=int(fold["kt_real"]),
                              child_tab=None if fold.get("child_tab") is None else
                              _dev(np.ascontiguousarray(fold["child_tab"], dtype=np.int32).reshape(-1), device),
-                             child_side=int(fold.get("child_side", 0)))
+                             child_side=int(fold.get("child_side", 0)),
+                             child_scale=None if fold.get("child_scale") is None else
+                             torch.as_tensor(np.ascontiguousarray(fold["child_scale"], dtype=np.float32)).to(device))
         self.row_id = _dev(groups.row_id, device)
         self.chan_id = _dev(groups.chan_id, device)
         self.g_nc4 = _dev(groups.g_nc4, device)
@@ -94,7 +96,10 @@ class _Side:
         if bias_rows is None:
             self.bias_idx = self.row_id
         else:
-            self.bias_idx = _dev(np.where(ri >= 0, bias_rows[np.maximum(ri, 0)], -1).astype(np.int32), device)
+            self.bias_idx = _dev(np.where(ri >= 0, np.asarray(bias_rows)[np.maximum(ri, 0)], -1).astype(np.int32), device)
+        self.bias_idx2 = None
+        if bias_rows2 is not None:
+            self.bias_idx2 = _dev(np.where(ri >= 0, np.asarray(bias_rows2)[np.maximum(ri, 0)], -1).astype(np.int32), device)
         p_off, p_len, flat = P.flatten_pairs(pairs)
         self.pairs_host = pairs
         self._items = {}
@@ -124,7 +129,8 @@ class _Side:
                            None if f is None else _lib.ptr(f["coefs"]),
                            None if f is None or f["child_tab"] is None else _lib.ptr(f["child_tab"]),
                            1 if f is None else f["nf"], 0 if f is None else f["kt_real"],
-                           0 if f is None else f["child_side"], 0)
+                           0 if f is None else f["child_side"], 0,
+                           None if f is None or f["child_scale"] is None else _lib.ptr(f["child_scale"]))
 
     def pack_cb(self):
         """4-channel steps per pack workgroup: 4, fewer when the image of a step is large (many virtual taps)."""
@@ -209,7 +215,8 @@ class _Side:
                            _lib.ptr(plan["win_rows"]), _lib.ptr(plan["items"]), _lib.ptr(sc["segs"]), _lib.ptr(sc["worker_seg"]),
                            _lib.ptr(sc["fixups"]), _lib.ptr(sc["scratch"]), g.n_groups, g.kt, int(bp), plan["n_chunks"],
                            plan["ts"], plan["win"], int(g.g_nc4.max()), plan["max_items"], plan["un"], sc["n_workers"],
-                           sc["n_fixups"], sc["lds_floor"], self.src_ts, self.dst_ts, int(flags), float(slope))
+                           sc["n_fixups"], sc["lds_floor"], self.src_ts, self.dst_ts, int(flags), float(slope),
+                           _lib.ptr(self.bias_idx2))
         _lib.check(_lib.load().hmvae_gather_gemm_v3(C.byref(d), _lib.stream()), "gather_gemm_v3")
 
     def xcd_mode(self):
@@ -310,7 +317,7 @@ class _Side:
                            _lib.ptr(self.dst_rows), _lib.ptr(pb_off), _lib.ptr(pb_len), _lib.ptr(items), g.n_groups, g.mt,
                            g.kt, self.n_pos, int(bp), np_, n_pblk, n_units, ks, self.xcd_mode(), wpos, max_items, int(g.g_nc4.max()), self.src_ts,
                            self.dst_ts, int(flags),
-                           float(slope), _lib.ptr(DEBUG_BUF))
+                           float(slope), _lib.ptr(DEBUG_BUF), _lib.ptr(self.bias_idx2))
         _lib.check(lib.hmvae_gather_gemm_v2(C.byref(d), _lib.stream()), "gather_gemm_v2")
 
     def run_v1(self, src, dst, bp, bias=None, flags=0, slope=0.2):
@@ -357,52 +364,108 @@ class MaskedGemm:
             # taps; the weight gradient below keeps the plain relation on `x` (the conv's own input).
             pe, n_vt = comp["pairs_eff"], int(comp["taps"].shape[0])
             cmap = comp.get("cmap")                       # fine input channel -> source channel, or None
+            rmap = comp.get("rmap")                       # conv output row -> pooled output row, or None
+            assert cmap is None or rmap is None
             src_base = np.asarray(comp["src_base"], dtype=np.int64)
             src_ts = int(comp.get("src_ts", x_ts))
+            dst_base = np.asarray(comp.get("dst_base", y_base), dtype=np.int64)     # rows of the gather sides' output
             fold = dict(taps=comp["taps"], coefs=comp["coefs"], kt_real=kt)
-            if cmap is None:
-                gfe = P.make_groups(rows_f, chans_f, n_vt)
-                ffold = dict(fold)
-            else:
-                rf, cf, bits, children = P.merge_channels(rows_f, chans_f, cmap)
-                gfe = P.make_groups(rf, cf, n_vt, pair_bits=bits)
-                ctab = -np.ones((len(src_base), 4), dtype=np.int32)
+            b1 = b2 = None
+            if bias_rows is not None:
+                b1 = bias_rows
+            ctab = None
+
+            def child_table(children, n):
+                t = -np.ones((n, 4), dtype=np.int32)
                 for cc, fl in children.items():
                     assert len(fl) <= 4
-                    ctab[cc, :len(fl)] = fl
+                    t[cc, :len(fl)] = fl
+                return t
+            if cmap is not None:
+                rf, cf, bits, children = P.merge_channels(rows_f, chans_f, cmap)
+                gfe = P.make_groups(rf, cf, n_vt, pair_bits=bits)
+                ctab = child_table(children, len(src_base))
                 ffold = dict(fold, child_tab=ctab, child_side=0)
-            self.fwd = _Side(device, gfe, pe, src_base, y_base, bias_rows, src_ts, y_ts, (n_chan * kt, kt, 1), fold=ffold)
+            elif rmap is not None:
+                rf, cf, bits, children = P.merge_rows(rows_f, chans_f, rmap)
+                gfe = P.make_groups(rf, cf, n_vt, pair_bits=bits)
+                ctab = child_table(children, len(dst_base))
+                if max(len(v) for v in children.values()) > 2:
+                    raise NotImplementedError("pooled rows with more than two children")
+                scale = np.ones(len(dst_base), dtype=np.float32)
+                b1 = np.zeros(len(dst_base), dtype=np.int64)
+                b2 = -np.ones(len(dst_base), dtype=np.int64)
+                for pr, fl in children.items():
+                    scale[pr] = 1.0 / len(fl)
+                    b1[pr] = fl[0]
+                    if len(fl) > 1:
+                        b2[pr] = fl[1]
+                ffold = dict(fold, child_tab=ctab, child_side=1, child_scale=scale)
+            else:
+                gfe = P.make_groups(rows_f, chans_f, n_vt)
+                ffold = dict(fold)
+            self.fwd = _Side(device, gfe, pe, src_base, dst_base, b1, src_ts, y_ts, (n_chan * kt, kt, 1), fold=ffold,
+                             bias_rows2=b2)
             if rows_b is not None:
                 pb = P.transpose_pairs(pe, int(comp["n_src_pos"]))
-                if cmap is None:
-                    gbe = P.make_groups(rows_b, chans_b, n_vt)
-                    bfold = dict(fold)
-                else:
-                    rb, cb_, bits_b, children = P.merge_channels_transposed(rows_b, chans_b, cmap, len(src_base))
+                if cmap is not None:
+                    rb, cb_, bits_b, _ = P.merge_channels_transposed(rows_b, chans_b, cmap, len(src_base))
                     gbe = P.make_groups(rb, cb_, n_vt, pair_bits=bits_b)
                     bfold = dict(fold, child_tab=ctab, child_side=1)
-                self.bwd = _Side(device, gbe, pb, y_base, src_base, None, y_ts, src_ts, (kt, n_chan * kt, 1), fold=bfold)
+                elif rmap is not None:
+                    rb, cb_, bits_b, _ = P.merge_rows_transposed(rows_b, chans_b, rmap)
+                    gbe = P.make_groups(rb, cb_, n_vt, pair_bits=bits_b)
+                    bfold = dict(fold, child_tab=ctab, child_side=0, child_scale=scale)
+                else:
+                    gbe = P.make_groups(rows_b, chans_b, n_vt)
+                    bfold = dict(fold)
+                self.bwd = _Side(device, gbe, pb, dst_base, src_base, None, y_ts, src_ts, (kt, n_chan * kt, 1), fold=bfold)
         # weight gradient tiles: forward grouping, or (masked convs) a grouping keyed by input block whose tiles have
         # several 16-row pieces per activation load and no union waste
         gw = gf
-        if rows_b is not None and len(rows_b) > 1 and _os.environ.get("HMVAE_WGRAD_G", "1") != "0":
+        self.wg_child = None                 # (child_tab, child_side, child_scale) of a deduplicated weight gradient
+        wg_x_base, wg_dz_base = x_base, y_base
+        dedupe = (comp is not None and rows_b is not None and (comp.get("cmap") is not None or comp.get("rmap") is not None)
+                  and _os.environ.get("HMVAE_WGRAD_DEDUPE", "1") != "0")
+        if dedupe:
+            # Copies of one coarse channel (SkeletonUnpool) see the same activations and rows averaged by SkeletonPool the
+            # same output gradient: compute their weight gradients once (tiles over the merged ids) and let the reduce
+            # write every child (hmvae_wreduce_desc).
+            if comp.get("cmap") is not None:
+                rc, cc_, bits_b, ch_ = P.merge_channels_transposed(rows_b, chans_b, comp["cmap"], len(comp["src_base"]))
+                gw = P.make_wgrad_groups(rc, cc_, kt, pair_bits=lambda r, c, _b=bits_b: _b(c, r))
+                wg_x_base = np.zeros(len(comp["src_base"]), dtype=np.int64)
+                for c_, fl in ch_.items():
+                    wg_x_base[c_] = x_base[fl[0]]              # every child holds the same rows of the conv's input
+                self.wg_child = (_dev(ctab.reshape(-1), device), 0, None)
+            else:
+                rb_, cp_, bits_r, ch_ = P.merge_rows_transposed(rows_b, chans_b, comp["rmap"])
+                gw = P.make_wgrad_groups(rb_, cp_, kt, pair_bits=lambda r, c, _b=bits_r: _b(c, r))
+                wg_dz_base = dst_base                          # the gradient w.r.t. the POOLED pre-activation
+                self.wg_child = (_dev(ctab.reshape(-1), device), 1,
+                                 torch.as_tensor(np.ascontiguousarray(scale, dtype=np.float32)).to(device))
+                self.pool_scale = scale
+                self.pool_rmap = np.asarray(comp["rmap"], dtype=np.int64)
+                self.pool_dst_base = dst_base
+        elif rows_b is not None and len(rows_b) > 1 and _os.environ.get("HMVAE_WGRAD_G", "1") != "0":
             cand = P.make_wgrad_groups(rows_b, chans_b, kt)
             t_f = sum(-(-int(nn) * kt // 64) for nn in gf.g_nch) * gf.mt * (1.0 + 0.35 / gf.mt)
             t_c = sum(-(-int(nn) * kt // 64) for nn in cand.g_nch) * cand.mt * (1.0 + 0.35 / cand.mt)
             if t_c < t_f:
                 gw = cand
         self.wg = gw
+        self.wg_pooled_dz = dedupe and comp.get("rmap") is not None      # backward_weight takes the pooled gradient
         self.wg_tabs = dict(row_id=_dev(gw.row_id, device), chan_id=_dev(gw.chan_id, device), g_nc4=_dev(gw.g_nc4, device),
                             g_choff=_dev(gw.g_choff, device), g_okoff=_dev(gw.g_okoff, device),
                             pair_ok=_dev(gw.pair_ok, device))
         chw = gw.chan_id
-        self.wg_chan_rows = _dev(np.where(chw >= 0, x_base[np.maximum(chw, 0)], x_base[int(chw[chw >= 0][0])]).astype(np.int32),
-                                 device)
+        self.wg_chan_rows = _dev(np.where(chw >= 0, wg_x_base[np.maximum(chw, 0)],
+                                          wg_x_base[int(chw[chw >= 0][0])]).astype(np.int32), device)
         tile_g, tile_col0, g_ncols = gw.wgrad_tiles()
         self.n_tiles = len(tile_g)
         self.tile_g, self.tile_col0, self.g_ncols = _dev(tile_g, device), _dev(tile_col0, device), _dev(g_ncols, device)
         ri = gw.row_id
-        self.dz_rows = _dev(np.where(ri >= 0, y_base[np.maximum(ri, 0)], -1).astype(np.int32), device)
+        self.dz_rows = _dev(np.where(ri >= 0, wg_dz_base[np.maximum(ri, 0)], -1).astype(np.int32), device)
         self.x_ts, self.y_ts = int(x_ts), int(y_ts)
         # geometry of the position reduction for the weight gradient
         self.geom = conv_geom or dict(t_dst=len(pairs_f), t_src=len(pairs_f), stride=1, pad=0, pad_mode=_lib.PAD_REFLECT)
@@ -523,7 +586,10 @@ class MaskedGemm:
                                 _lib.ptr(self.g_ncols), _lib.ptr(tb["g_choff"]), _lib.ptr(tb["chan_id"]),
                                 _lib.ptr(tb["row_id"]), _lib.ptr(tb["g_nc4"]), _lib.ptr(tb["g_okoff"]),
                                 _lib.ptr(tb["pair_ok"]), self.n_tiles, g.mt, g.kt, ns, n_chan * kt, kt,
-                                1 if accumulate else 0)
+                                1 if accumulate else 0,
+                                None if self.wg_child is None else _lib.ptr(self.wg_child[0]),
+                                None if self.wg_child is None or self.wg_child[2] is None else _lib.ptr(self.wg_child[2]),
+                                0 if self.wg_child is None else self.wg_child[1], 0)
 
     def reduce_rows(self):
         return (self.bwd.g.mt if self.wg_transposed else self.wg.mt) * 16
@@ -569,7 +635,7 @@ MaskedGemm._wgrad_gemm_t = _mg_wgrad_gemm_t
 
 
 def conv_gemm(device, neigh, cin, cout, kt, stride, pad, pad_mode, t_in, need_dx=True, out_chan_map=None,
-              upsample=False, unpool_src=None):
+              upsample=False, unpool_src=None, pool_groups=None):
     """SkeletonConv (skeleton.py:9-105) as a MaskedGemm.  out_chan_map lets the output land in other channel
     slots (the decoder's per-edge concat, seq_two_hier_sa_vae.py:280-288).
 
@@ -579,7 +645,12 @@ def conv_gemm(device, neigh, cin, cout, kt, stride, pad, pad_mode, t_in, need_dx
     (t_in/2 positions, len(set(unpool_src)) edges): a polyphase filter with ~8 instead of 15 (position, tap) items per
     output position and the duplicated channels read once through summed weights.  forward()/backward_data() then take
     / return the COARSE tensor; backward_weight() still takes the conv's own (upsampled, unpooled) input.
-    Convolutions over fewer positions than taps get their taps folded the same way (FOLD)."""
+    Convolutions over fewer positions than taps get their taps folded the same way (FOLD).
+
+    pool_groups describes what FOLLOWS an encoder convolution (seq_two_hier_sa_vae.py:126-129): SkeletonPool, the mean
+    over the <= 2 edges of each group, then LeakyReLU.  The mean is linear, so forward (with the LeakyReLU flag) produces
+    the POOLED, activated tensor directly from row-averaged weights, and backward_data() takes the gradient w.r.t. the
+    pooled pre-activation; backward_weight() still takes the gradient w.r.t. the conv's own output rows."""
     t_out = (t_in + 2 * pad - kt) // stride + 1
     mode = "reflect" if pad_mode in ("reflect", "reflection") else "zeros"
     if mode == "reflect" and pad >= t_in and pad > 0:
@@ -596,7 +667,7 @@ def conv_gemm(device, neigh, cin, cout, kt, stride, pad, pad_mode, t_in, need_dx
     geom = dict(t_dst=t_out, t_src=t_in, stride=stride, pad=pad,
                 pad_mode=_lib.PAD_REFLECT if mode == "reflect" else _lib.PAD_ZEROS)
     composite = None
-    want = FOLD and ((upsample or unpool_src is not None) or t_in < kt)
+    want = FOLD and ((upsample or unpool_src is not None or pool_groups is not None) or t_in < kt)
     if want:
         t_src = t_in // 2 if upsample else t_in
         comp = P.compose_conv(pairs_f, P.upsample_rows(t_src) if upsample else None)
@@ -615,15 +686,32 @@ def conv_gemm(device, neigh, cin, cout, kt, stride, pad, pad_mode, t_in, need_dx
                     comp = None
             items_new = sum(len(l) for l in pe)
             items_old = sum(len(l) for l in pairs_f)
-            if comp is not None and (items_new < 0.9 * items_old or cmap is not None or upsample):
+            rmap = dst_base = None
+            if pool_groups is not None:
+                n_edges = len(neigh)
+                co = cout // n_edges
+                if out_chan_map is not None or any(len(g) > 2 for g in pool_groups) or \
+                        sorted(j for g in pool_groups for j in g) != list(range(n_edges)):
+                    comp = None
+                else:
+                    dst_e = np.zeros(n_edges, dtype=np.int64)
+                    for i, grp in enumerate(pool_groups):
+                        for j in grp:
+                            dst_e[j] = i
+                    rmap = (dst_e[:, None] * co + np.arange(co)[None, :]).reshape(-1)
+                    dst_base = np.arange(len(pool_groups) * co, dtype=np.int64) * t_out
+            if comp is not None and (items_new < 0.9 * items_old or cmap is not None or upsample or rmap is not None):
                 composite = dict(pairs_eff=pe, taps=taps, coefs=coefs, cmap=cmap, n_src_pos=t_src,
                                  src_base=np.arange(n_src_ch, dtype=np.int64) * t_src, src_ts=1)
-    if composite is None and (upsample or unpool_src is not None):
-        raise _lib.HmvaeError("upsample/unpool in front of this convolution cannot be folded (HMVAE_FOLD=0 or limits)")
+                if rmap is not None:
+                    composite.update(rmap=rmap, dst_base=dst_base)
+    if composite is None and (upsample or unpool_src is not None or pool_groups is not None):
+        raise _lib.HmvaeError("the layers around this convolution cannot be folded into it (HMVAE_FOLD=0 or limits)")
     op = MaskedGemm(device, (cout, cin, kt), rows_f, chans_f, rows_b, chans_b, pairs_f, pairs_b, x_base, y_base, 1, 1,
                     conv_geom=geom, composite=composite)
     op.t_in, op.t_out = t_in, t_out
     op.fused_front = bool(upsample or unpool_src is not None)
+    op.fused_pool = pool_groups is not None
     return op
 
 
@@ -718,6 +806,11 @@ def leaky_bwd(dout, out, dy, n, slope=0.2, n_blocks=1, block_stride=None):
 def row_sums(src, dst, rows, n_out, rows_per_out, row_step, n_cols, accumulate=False):
     _lib.check(_lib.load().hmvae_row_sums(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(rows), n_out, rows_per_out, row_step,
                                           n_cols, 1 if accumulate else 0, _lib.stream()), "row_sums")
+
+
+def row_sums_scaled(src, dst, rows, scale, n_out, rows_per_out, row_step, n_cols):
+    _lib.check(_lib.load().hmvae_row_sums_scaled(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(rows), _lib.ptr(scale), n_out,
+                                                 rows_per_out, row_step, n_cols, _lib.stream()), "row_sums_scaled")
 
 
 def reparam_kl_fwd(dist, eps, z, kl_partial, k_edges, d, B, bp, sample=True):

@@ -166,7 +166,7 @@ def conv_joint_lists_transposed(neigh, cin, cout):
     return rows, [sorted(c) for c in chans]
 
 
-def make_wgrad_groups(rows_b, chans_b, kt, mt_choices=(4, 3, 2, 1)):
+def make_wgrad_groups(rows_b, chans_b, kt, mt_choices=(4, 3, 2, 1), pair_bits=None):
     """Weight-gradient tiling keyed by INPUT block: columns = the block's channels x taps, rows = every output row
     that reads the block (all of them read all of its channels, so there is no union waste), cut into 16*mt-row
     pieces.  rows_b / chans_b are the transposed lists (conv_joint_lists_transposed): rows_b[k] = channels of input
@@ -183,7 +183,13 @@ def make_wgrad_groups(rows_b, chans_b, kt, mt_choices=(4, 3, 2, 1)):
             per = -(-per // 16) * 16 if per % 16 else per
             for k in range(0, len(out_rows), per):
                 groups.append((out_rows[k:k + per], list(in_ch)))
-        gs = GroupSet(mt, groups, kt, None)
+        row_chans = None
+        if pair_bits is not None:           # merged ids: a row reads a listed channel through some of its children only
+            row_chans = {}
+            for out_rows, in_ch in groups:
+                for r in out_rows:
+                    row_chans[r] = row_chans.get(r, frozenset()) | frozenset(c for c in in_ch if pair_bits(r, c))
+        gs = GroupSet(mt, groups, kt, row_chans, pair_bits)
         tiles = sum(-(-int(n) * kt // 64) for n in gs.g_nch)
         cost = tiles * mt * (1.0 + 0.35 / mt)          # fewer, fatter tiles reuse the activation operand more
         if best is None or cost < best[0]:
@@ -582,3 +588,49 @@ def merge_channels_transposed(rows_b, chans_b, cmap, n_coarse):
     def bits(cc, r):
         return sum(1 << i for i, f in enumerate(children[cc]) if r in reads[f])
     return rows_c, chans_c, bits, children
+
+
+def merge_rows(joint_rows, joint_chans, rmap):
+    """Forward lists with the output rows replaced by the pooled rows they are averaged into (rmap[fine row] = pooled
+    row, SkeletonPool folded into the weights).  Blocks: pooled rows whose children sit in the same fine blocks.
+    Returns (rows_p, chans_p, pair_bits, children) -- pair_bits(pooled row, chan): bit i set when child i of the pooled
+    row reads that channel."""
+    children = {}
+    for r, pr in enumerate(rmap):
+        children.setdefault(int(pr), []).append(r)
+    blk_of_row, reads = {}, {}
+    for bi, (rows, chans) in enumerate(zip(joint_rows, joint_chans)):
+        fs = frozenset(chans)
+        for r in rows:
+            blk_of_row[r] = bi
+            reads[r] = fs
+    blocks = {}
+    for pr in sorted(children):
+        key = tuple(sorted(set(blk_of_row[r] for r in children[pr])))
+        blocks.setdefault(key, []).append(pr)
+    rows_p, chans_p = [], []
+    for key in sorted(blocks):
+        rows_p.append(blocks[key])
+        chans_p.append(sorted(set().union(*[reads[r] for pr in blocks[key] for r in children[pr]])))
+
+    def bits(pr, c):
+        return sum(1 << i for i, r in enumerate(children[pr]) if c in reads[r])
+    return rows_p, chans_p, bits, children
+
+
+def merge_rows_transposed(rows_b, chans_b, rmap):
+    """Transposed lists (rows = input channels, channels = output rows reading them) with the output rows merged into
+    pooled rows: pair_bits(input channel, pooled row) = which children of the pooled row read the channel."""
+    children = {}
+    for r, pr in enumerate(rmap):
+        children.setdefault(int(pr), []).append(r)
+    readers = {}
+    for rows, chans in zip(rows_b, chans_b):
+        fs = frozenset(chans)
+        for f in rows:
+            readers[f] = fs
+    chans_p = [sorted(set(int(rmap[r]) for r in chans)) for chans in chans_b]
+
+    def bits(f, pr):
+        return sum(1 << i for i, r in enumerate(children[pr]) if r in readers[f])
+    return rows_b, chans_p, bits, children

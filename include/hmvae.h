@@ -97,6 +97,8 @@ typedef struct {
     int32_t flags;
     float slope;
     uint64_t* debug;         /* NULL in production; a diagnostic build (-DHMVAE_STAMP) writes 4 s_memtime stamps per wave */
+    const int32_t* bias_idx2;/* NULL, or a second bias index per packed row (-1: none): bias = mean of the two (rows that
+                                are the mean of two dense rows: SkeletonPool folded into the convolution) */
 } hmvae_gemm2_desc;
 
 int hmvae_gather_gemm_v2(const hmvae_gemm2_desc* desc, hmvae_stream_t stream);
@@ -144,6 +146,7 @@ typedef struct {
                                 was made for); 0 = only what the kernel needs */
     int32_t src_ts, dst_ts, flags;
     float slope;
+    const int32_t* bias_idx2;/* as in hmvae_gemm2_desc */
 } hmvae_conv3_desc;
 
 int hmvae_gather_gemm_v3(const hmvae_conv3_desc* desc, hmvae_stream_t stream);
@@ -193,6 +196,14 @@ typedef struct {
     int32_t n_tiles, mt, kt, n_split;
     int32_t row_stride, chan_stride;
     int32_t accumulate;
+    /* Deduplicated weight gradients (composite ops, see hmvae_pack_op): copies of one coarse channel (SkeletonUnpool) see
+     * the same activations, rows averaged by SkeletonPool the same output gradient, so their weight gradients are
+     * computed once.  With child_tab, an element is written to every child i (child_tab[id*4 + i], replacing the
+     * channel index for child_side 0, the row index for child_side 1) whose bit is set in pair_ok, times
+     * child_scale[id] (the mean's 1/n) when given. */
+    const int32_t* child_tab;
+    const float* child_scale;
+    int32_t child_side, pad_;
 } hmvae_wreduce_desc;
 
 int hmvae_wgrad_reduce(const hmvae_wreduce_desc* desc, hmvae_stream_t stream);
@@ -238,6 +249,7 @@ typedef struct {
     const float* fold_coef;     /* [kt][fold_nf] */
     const int32_t* child_tab;   /* [n][4] or NULL */
     int32_t fold_nf, fold_kt, child_side, fold_pad;
+    const float* child_scale;   /* NULL, or a factor per packed id on the child side (1/2: the mean of two children) */
 } hmvae_pack_op;
 
 /* One workgroup per (group, cb consecutive 4-channel steps): op i owns the blocks block_start ..
@@ -272,6 +284,9 @@ int hmvae_leaky_bwd(const float* dout, const float* out, float* dy, int64_t bloc
  * columns are zero by construction) */
 int hmvae_row_sums(const float* src, float* dst, const int32_t* rows, int32_t n_out, int32_t rows_per_out,
                    int32_t row_step, int32_t n_cols, int32_t accumulate, hmvae_stream_t stream);
+/* the same with a factor per output (scale[o] * sum): bias gradients of rows that were averaged by SkeletonPool */
+int hmvae_row_sums_scaled(const float* src, float* dst, const int32_t* rows, const float* scale, int32_t n_out,
+                          int32_t rows_per_out, int32_t row_step, int32_t n_cols, hmvae_stream_t stream);
 /* Several row-sum jobs (bias gradients) in one launch; one workgroup per output element. */
 typedef struct {
     const float* src;

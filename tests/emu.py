@@ -43,6 +43,8 @@ def emu_pack(side, dense):
                                     else:
                                         dc = ctab[cid, ci]
                                 real += np.array([dense[dr * rs + dc * cs + k * ts] for k in range(kr)], dtype=np.float32)
+                            if fold.get("child_scale") is not None:
+                                real *= _np(fold["child_scale"])[rid if fold["child_side"] else cid]
                             vals = [np.float32(sum(coefs[vt, j] * real[taps[vt, j]] for j in range(nf) if taps[vt, j] >= 0))
                                     for vt in range(g.kt)]
                         for tap in range(g.kt):
@@ -55,6 +57,7 @@ def emu_gather(side, wp, src, dst, bias=None, leaky=False, accum=False, slope=0.
     g = side.g
     chan_rows, dst_rows = _np(side.chan_rows), _np(side.dst_rows)
     bias_idx = _np(side.bias_idx)
+    bias_idx2 = None if getattr(side, "bias_idx2", None) is None else _np(side.bias_idx2)
     p_off, p_len, pairs = _np(side.p_off), _np(side.p_len), _np(side.pairs)
     R = g.mt * 16
     for gi in range(g.n_groups):
@@ -76,7 +79,10 @@ def emu_gather(side, wp, src, dst, bias=None, leaky=False, accum=False, slope=0.
                     continue
                 v = acc[r]
                 if bias is not None and bias_idx[gi * R + r] >= 0:
-                    v = v + bias[bias_idx[gi * R + r]]
+                    bv = bias[bias_idx[gi * R + r]]
+                    if bias_idx2 is not None and bias_idx2[gi * R + r] >= 0:      # mean of two dense rows (pool folded in)
+                        bv = 0.5 * (bv + bias[bias_idx2[gi * R + r]])
+                    v = v + bv
                 if leaky:
                     v = np.where(v > 0, v, v * slope)
                 row = dr + p * side.dst_ts
@@ -113,6 +119,17 @@ def emu_wgrad(op, dy, x, dw):
                         if dz_rows[gi * R + r] >= 0:
                             acc[r] += float(np.dot(dy[dz_rows[gi * R + r] + t * op.y_ts].astype(np.float64), xv))
                 for r in range(R):
-                    if row_id[gi, r] >= 0 and g.pair_ok[g.g_okoff[gi] + r * (int(g.g_nc4[gi]) * 4) + ci]:
+                    bits = int(g.pair_ok[g.g_okoff[gi] + r * (int(g.g_nc4[gi]) * 4) + ci])
+                    if row_id[gi, r] < 0 or not bits:
+                        continue
+                    child = getattr(op, "wg_child", None)
+                    if child is None:
                         dwf[row_id[gi, r], cid, tap] = acc[r]
+                        continue
+                    ctab, side, scale = _np(child[0]).reshape(-1, 4), child[1], child[2]
+                    rid = row_id[gi, r]
+                    v = acc[r] * (float(_np(scale)[rid if side else cid]) if scale is not None else 1.0)
+                    for k in range(4):          # one computed gradient, several dense owners (hmvae_wreduce_desc)
+                        if (bits >> k) & 1:
+                            dwf[ctab[rid, k] if side else rid, cid if side else ctab[cid, k], tap] = v
     return dw

@@ -145,6 +145,56 @@ def test_conv_behind_upsample_unpool_reproduces_oracle(case):
     assert rel_err(dw, (w.grad * mask).numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("case", [
+    dict(level=0, ci=2, co=3, K=15, s=2, T=16),      # enc0-like: 24 edges pooled to 14
+    dict(level=2, ci=2, co=2, K=15, s=2, T=8),       # short sequence: taps folded as well
+    dict(level=1, ci=1, co=2, K=5, s=1, T=6),
+])
+def test_conv_followed_by_pool_reproduces_oracle(case):
+    """SkeletonPool (mean of <= 2 edges) + LeakyReLU folded into the convolution (planner.merge_rows): forward gives
+    the pooled activated tensor, backward-data takes the gradient w.r.t. the pooled pre-activation."""
+    torch.manual_seed(7 + case["level"])
+    edges = topology.edges_from_parents(topology.SMPL24_PARENTS)
+    for _ in range(case["level"]):
+        edges = topology.derive_pooling(edges)[2]
+    pooling = topology.derive_pooling(edges)[1]
+    neigh = topology.find_neighbor(edges, 2)
+    n_f, n_p = len(neigh), len(pooling)
+    K, st, T = case["K"], case["s"], case["T"]
+    cin, cout, co = n_f * case["ci"], n_f * case["co"], case["co"]
+    pad, B = (K - 1) // 2, 3
+    mask = O.conv_mask(neigh, cin, cout, K)
+    w = (torch.randn(cout, cin, K) * mask).requires_grad_(True)
+    b = torch.randn(cout, requires_grad=True)
+    x = torch.randn(B, cin, T, requires_grad=True)
+    y = O.skel_conv(x, w, mask, b, st, pad, "reflect")
+    y.retain_grad()
+    T_out = y.shape[2]
+    Pm = torch.zeros(n_p * co, cout)
+    for i, grp in enumerate(pooling):
+        for j in grp:
+            for c in range(co):
+                Pm[i * co + c, j * co + c] = 1.0 / len(grp)
+    pre = torch.einsum("pr,brt->bpt", Pm, y)
+    pre.retain_grad()
+    a = F.leaky_relu(pre, 0.2)
+    ga = torch.randn_like(a)
+    a.backward(ga)
+    op = ops.conv_gemm("cpu", neigh, cin, cout, K, st, pad, "reflect", T, need_dx=True, pool_groups=pooling)
+    assert op.folded and op.fused_pool
+    As = np.zeros((n_p * co * T_out, ops.pad_batch(B)), dtype=np.float32)
+    emu_gather(op.fwd, emu_pack(op.fwd, w.detach().numpy()), to_soa(x.detach()), As, bias=b.detach().numpy(), leaky=True)
+    assert rel_err(from_soa(As, B, n_p * co, T_out).numpy(), a.detach().numpy()) < 1e-5
+    dxs = np.zeros((cin * T, ops.pad_batch(B)), dtype=np.float32)
+    emu_gather(op.bwd, emu_pack(op.bwd, w.detach().numpy()), to_soa(pre.grad), dxs)
+    assert rel_err(from_soa(dxs, B, cin, T).numpy(), x.grad.numpy()) < 1e-5
+    dw = np.zeros((cout, cin, K), dtype=np.float32)
+    # the rows a pool group averages share their gradient: the deduplicated weight gradient takes the pooled one
+    emu_wgrad(op, to_soa(pre.grad if op.wg_pooled_dz else y.grad), to_soa(x.detach()), dw)
+    assert op.wg_pooled_dz
+    assert rel_err(dw, (w.grad * mask).numpy()) < 1e-5
+
+
 def test_linear_tables_reproduce_oracle():
     torch.manual_seed(5)
     B, k_edges, n_in, n_out = 5, 3, 12, 20
