@@ -545,9 +545,15 @@ extern "C" int hmvae_pack_weights(const float* dense, float* packed, const int32
 // once -- summed over the dense pairs merged into it -- and build all virtual taps from that.
 __global__ __launch_bounds__(256) void pack_multi_kernel(const hmvae_pack_op* __restrict__ ops, int n_ops) {
     extern __shared__ float img[];                    // [cb][kt][mt][64]
-    int oi = 0;
-    for (int i = 1; i < n_ops; ++i)
-        if ((int)blockIdx.x >= ops[i].block_start) oi = i;          // uniform scan over <= a few dozen entries
+    // which op owns this block: one lane-indexed load of the (<= 64) block_start fields + a ballot, instead of a serial
+    // scan whose n_ops dependent loads were most of a small block's life
+    int oi;
+    {
+        const int lane = threadIdx.x & 63;
+        const int st = lane < n_ops ? ops[lane].block_start : 0x7fffffff;
+        const unsigned long long m = __ballot((int)blockIdx.x >= st);
+        oi = __popcll(m) - 1;
+    }
     const hmvae_pack_op o = ops[oi];
     const int local = blockIdx.x - o.block_start;
     const int cb = o.cb;
@@ -586,30 +592,34 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const hmvae_pack_op* __
             for (int tap = 0; tap < kt; ++tap) dsti[tap * mt * 64] = ok ? src[(size_t)tap * o.tap_stride] : 0.f;
         }
     } else {
-        const int kr = o.fold_kt;                              // taps of the dense tensor
+        // Composite op.  A thread keeps the (<= 16) real taps of one (row, channel) pair in registers -- summed over the
+        // dense pairs merged into it -- and produces its virtual taps as a small dense product with the coefficient
+        // matrix C[vt][k] (built in LDS from the sparse tables, read back as broadcast float4s): no index chasing.
+        // (Chasing table -> tap -> staged value per term was a serial chain of LDS round trips: 3/4 of the kernel.)
+        const int kr = o.fold_kt;                              // taps of the dense tensor (host checks kr <= 16)
         const int nf = o.fold_nf;
-        float* stage = img + cb * step_floats;                 // [step][pair][kr], private to the owning thread
-        int* ftaps = (int*)(stage + cb * ppc * kr);            // [kt][nf]
-        float* fcoef = (float*)(ftaps + kt * nf);
+        float* ct = img + cb * step_floats;                    // [kt][16]
+        for (int i = tid; i < kt * 16; i += 256) ct[i] = 0.f;
+        __syncthreads();
         for (int i = tid; i < kt * nf; i += 256) {
-            ftaps[i] = o.fold_taps[i];
-            fcoef[i] = o.fold_coef[i];
+            const int k = o.fold_taps[i];
+            if (k >= 0) ct[(i / nf) * 16 + k] = o.fold_coef[i];          // a tap appears once per virtual tap
         }
         __syncthreads();
-        for (int pi = tid; pi < ncb * ppc; pi += 256) {
+        const int np = ncb * ppc;                              // pairs of this block: 64..256
+        const int rep = np <= 128 ? (np <= 64 ? 4 : 2) : 1;    // threads per pair (they split the virtual taps)
+        const int pi = tid % np, part = tid / np;
+        if (part < rep) {
             const int st = pi / ppc, pair = pi - st * ppc, c4 = c40 + st;
             int r, kk;
             pair_rk(pair, r, kk);
             const int rid = o.row_id[g * rows + r];
             const int cid = o.chan_id[o.g_choff[g] + c4 * 4 + kk];
             const unsigned bits = (rid >= 0 && cid >= 0) ? o.pair_ok[o.g_okoff[g] + r * (nc4 * 4) + c4 * 4 + kk] : 0u;
-            float* dsti = img + st * step_floats + (r >> 4) * 64 + kk * 16 + (r & 15);
-            if (!bits) {
-                for (int vt = 0; vt < kt; ++vt) dsti[vt * mt * 64] = 0.f;
-                continue;
-            }
-            float* mine = stage + pi * kr;
-            for (int k = 0; k < kr; ++k) mine[k] = 0.f;
+            float t[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t[k] = 0.f;
+#pragma unroll
             for (int ci = 0; ci < 4; ++ci) {                   // dense (row, channel) pairs merged into this one
                 if (!((bits >> ci) & 1u)) continue;
                 int dr = rid, dc = cid;
@@ -618,18 +628,23 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const hmvae_pack_op* __
                     else dc = o.child_tab[cid * 4 + ci];
                 }
                 const float* src = o.dense + (size_t)dr * o.row_stride + (size_t)dc * o.chan_stride;
-                for (int k = 0; k < kr; ++k) mine[k] += src[(size_t)k * o.tap_stride];
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < kr) t[k] += src[(size_t)k * o.tap_stride];
             }
-            if (o.child_scale) {                               // e.g. 1/2: the packed row is the MEAN of its children
+            if (bits && o.child_scale) {                       // e.g. 1/2: the packed row is the MEAN of its children
                 const float sc = o.child_scale[o.child_side ? rid : cid];
-                for (int k = 0; k < kr; ++k) mine[k] *= sc;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) t[k] *= sc;
             }
-            for (int vt = 0; vt < kt; ++vt) {
+            float* dsti = img + st * step_floats + (r >> 4) * 64 + kk * 16 + (r & 15);
+            const int v0 = part * kt / rep, v1 = (part + 1) * kt / rep;
+            for (int vt = v0; vt < v1; ++vt) {
+                const f32x4* c = (const f32x4*)(ct + vt * 16);
+                const f32x4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
                 float v = 0.f;
-                for (int j = 0; j < nf; ++j) {
-                    const int k = ftaps[vt * nf + j];
-                    if (k >= 0) v += fcoef[vt * nf + j] * mine[k];
-                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v += t[k] * c0[k] + t[4 + k] * c1[k] + t[8 + k] * c2[k] + t[12 + k] * c3[k];
                 dsti[vt * mt * 64] = v;
             }
         }
@@ -642,7 +657,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const hmvae_pack_op* __
 
 extern "C" int hmvae_pack_weights_multi(const hmvae_pack_op* ops_dev, int32_t n_ops, int32_t total_blocks,
                                         int32_t max_lds_floats, hmvae_stream_t stream) {
-    if (!ops_dev || n_ops <= 0 || total_blocks <= 0 || max_lds_floats <= 0) return HMVAE_ERR_ARG;
+    if (!ops_dev || n_ops <= 0 || n_ops > 64 || total_blocks <= 0 || max_lds_floats <= 0) return HMVAE_ERR_ARG;
     const size_t lds = (size_t)max_lds_floats * sizeof(float);
     if (lds > 64 * 1024) return HMVAE_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), lds, (hipStream_t)stream, ops_dev, n_ops);

@@ -88,7 +88,7 @@ class VaeEngine:
             # SkeletonPool + LeakyReLU are folded into the convolution's forward / backward-data GEMMs (ops.conv_gemm):
             # forward writes the pooled activated tensor A directly; the gradient w.r.t. the conv's own rows (dY) is only
             # built for the weight gradient, on its side stream
-            fuse = ops.FOLD and pool.covered and all(len(g) <= 2 for g in p.pooling[i])
+            fuse = ops.FOLD and p.K <= 16 and pool.covered and all(len(g) <= 2 for g in p.pooling[i])
             self.enc_conv.append(ops.conv_gemm(device, p.neigh[i], p.enc_cin[i], p.enc_cout[i], p.K, p.strides[i], p.pad,
                                                p.pad_mode, p.tsteps[i], need_dx=(i > 0),
                                                pool_groups=p.pooling[i] if fuse else None))
@@ -116,7 +116,7 @@ class VaeEngine:
             for ci, grp in enumerate(p.pooling[lvl]):
                 for j in grp:
                     usrc[j] = ci
-            fuse = ops.FOLD and bool(p.dec_up[i])
+            fuse = ops.FOLD and p.K <= 16 and bool(p.dec_up[i])
             self.dec_conv.append(ops.conv_gemm(device, p.neigh[lvl], p.dec_cin[i], p.dec_cout[i], p.K, 1, p.pad, p.pad_mode,
                                                t_conv, need_dx=True, out_chan_map=cmap, upsample=fuse,
                                                unpool_src=usrc if fuse else None))

@@ -69,6 +69,8 @@ class _Side:
         # composite one (virtual taps, merged channels; hmvae.h, hmvae_pack_op)
         self.fold = None
         if fold is not None:
+            if int(fold["kt_real"]) > 16:
+                raise _lib.HmvaeError("composite packs support at most 16 taps in the dense tensor")
             self.fold = dict(taps=_dev(np.ascontiguousarray(fold["taps"], dtype=np.int32).reshape(-1), device),
                              coefs=torch.as_tensor(np.ascontiguousarray(fold["coefs"], dtype=np.float32).reshape(-1)).to(device),
                              nf=int(fold["taps"].shape[1]), kt_real=int(fold["kt_real"]),
@@ -140,7 +142,7 @@ class _Side:
         g, cb = self.g, self.pack_cb()
         n = cb * g.kt * g.mt * 64
         if self.fold is not None:
-            n += cb * g.mt * 64 * self.fold["kt_real"] + 2 * g.kt * self.fold["nf"]
+            n += g.kt * 16          # the coefficient matrix C[vt][16]
         return n
 
     def pack_blocks(self):
@@ -549,6 +551,12 @@ class MaskedGemm:
     def autotune_split(self, dy, x, dw, bp, slab):
         if bp in self._split_tuned or not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return
+        ck = "wg_t%d_m%d_k%d_c%d_tr%d_b%d" % (self.n_tiles_t if self.wg_transposed else self.n_tiles, self.wg.mt, self.kt,
+                                             self._k_chunks(bp), int(self.wg_transposed), bp)
+        hit = _tune_cache_get(ck)
+        if hit is not None:
+            self._split_tuned[bp] = int(hit[0])
+            return
         scratch = torch.empty_like(dw)
         best = None
         torch.cuda.synchronize()                 # nothing else on the GPU while the candidates are timed
@@ -563,6 +571,7 @@ class MaskedGemm:
             if best is None or t < best[0]:
                 best = (t, c)
         self._split_tuned[bp] = best[1]
+        _tune_cache_put(ck, (best[1],))
 
     def backward_weight(self, dy, x, dw, bp, slab, accumulate=False):
         self.autotune_split(dy, x, dw, bp, slab)
@@ -667,10 +676,17 @@ def conv_gemm(device, neigh, cin, cout, kt, stride, pad, pad_mode, t_in, need_dx
     geom = dict(t_dst=t_out, t_src=t_in, stride=stride, pad=pad,
                 pad_mode=_lib.PAD_REFLECT if mode == "reflect" else _lib.PAD_ZEROS)
     composite = None
-    want = FOLD and ((upsample or unpool_src is not None or pool_groups is not None) or t_in < kt)
+    want = FOLD and kt <= 16 and ((upsample or unpool_src is not None or pool_groups is not None) or t_in < kt)
     if want:
         t_src = t_in // 2 if upsample else t_in
-        comp = P.compose_conv(pairs_f, P.upsample_rows(t_src) if upsample else None)
+        if upsample or t_in < kt:
+            comp = P.compose_conv(pairs_f, P.upsample_rows(t_src) if upsample else None)
+        else:       # nothing to fold in time: identity virtual taps (only rows / channels are merged)
+            taps_id = -np.ones((kt, 4), dtype=np.int32)
+            taps_id[:, 0] = np.arange(kt)
+            coefs_id = np.zeros((kt, 4), dtype=np.float32)
+            coefs_id[:, 0] = 1.0
+            comp = (pairs_f, taps_id, coefs_id)
         if comp is not None:
             pe, taps, coefs = comp
             cmap = None

@@ -254,7 +254,7 @@ typedef struct {
 
 /* One workgroup per (group, cb consecutive 4-channel steps): op i owns the blocks block_start ..
  * block_start + n_groups*ceil(max_nc4/cb).  max_lds_floats: the largest per-op LDS need, cb*kt*mt*64 floats, plus
- * cb*mt*64*fold_kt + 2*kt*fold_nf for a composite op */
+ * kt*16 for a composite op (fold_kt <= 16, 16-row groups) */
 int hmvae_pack_weights_multi(const hmvae_pack_op* ops_dev, int32_t n_ops, int32_t total_blocks, int32_t max_lds_floats,
                              hmvae_stream_t stream);
 

@@ -27,7 +27,7 @@ tot = {"fwd": 0, "bwd": 0, "wg": 0}
 print("B=%d bp=%d" % (B, bp))
 for name, op in zip(names, convs):
     cout, cin, kt = op.w_shape
-    x = torch.randn(cin * op.t_in, bp, device=dev); y = torch.empty(cout * op.t_out + 400000, bp, device=dev)
+    x = torch.randn(cin * op.t_in + 400000, bp, device=dev); y = torch.empty(cout * op.t_out + 400000, bp, device=dev)
     dy = torch.randn(y.shape[0], bp, device=dev); dx = torch.empty_like(x); dw = torch.zeros(cout, cin, kt, device=dev)
     slab = torch.empty(op.slab_floats(bp), device=dev)
     useful = 2.0 * op.useful_macs_per_col * bp
