@@ -189,8 +189,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
     // LDS: first the per-position activation offset table (during the reduction loop), then the cross-wave sums
     extern __shared__ __attribute__((aligned(16))) float red[];
     unsigned* xtab = (unsigned*)red;                  // [t_dst][64]: byte offset of column c's activation row at position t
-    const int tile = blockIdx.x % d.n_tiles;
-    const int sp = blockIdx.x / d.n_tiles;
+    // XCD-aware work order: XCD x (blockIdx % 8) takes a contiguous range of (tile, split) items, tile-major.  The tiles of
+    // one input block (same activation rows, different output-row pieces) are neighbours in that order, so an XCD's L2
+    // sees ~1/8 of the activations instead of all of them.
+    const int n_items = d.n_tiles * d.n_split;
+    const int per = (n_items + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || item >= n_items) return;
+    const int tile = item / d.n_split;
+    const int sp = item - tile * d.n_split;
     const int g = d.tile_g[tile];
     const int col0 = d.tile_col0[tile];
     const int lane = threadIdx.x & 63;
@@ -391,7 +398,7 @@ extern "C" int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t str
         const int npos = desc->transposed ? desc->t_src + 2 * desc->pad : desc->t_dst;
         if ((size_t)npos * 64 * sizeof(unsigned) > 64 * 1024) return HMVAE_ERR_UNSUPPORTED;       // position table in LDS
     }
-    dim3 grid((unsigned)nblk);
+    dim3 grid((unsigned)(((nblk + 7) / 8) * 8));
     hipStream_t s = (hipStream_t)stream;
     switch (desc->mt) {
         case 1: launch_wgrad<1>(desc, grid, s); break;

@@ -171,6 +171,9 @@ def make_wgrad_groups(rows_b, chans_b, kt, mt_choices=(4, 3, 2, 1), pair_bits=No
     that reads the block (all of them read all of its channels, so there is no union waste), cut into 16*mt-row
     pieces.  rows_b / chans_b are the transposed lists (conv_joint_lists_transposed): rows_b[k] = channels of input
     block k, chans_b[k] = output rows that read it.  Returns the GroupSet with the fewest MFMA tile-rows."""
+    import os
+    if os.environ.get("HMVAE_WGRAD_MT"):
+        mt_choices = tuple(int(c) for c in os.environ["HMVAE_WGRAD_MT"].split(","))
     best = None
     for mt in mt_choices:
         cap = 16 * mt

@@ -199,6 +199,62 @@ def test_conv_behind_upsample_unpool(dev, level, ch, co, Tc, B):
     assert float((dw.cpu() * (1 - mask)).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("level,ci,co,T,B", [(0, 6, 12, 64, 3), (2, 24, 48, 16, 70), (3, 48, 96, 8, 2)])
+def test_conv_followed_by_pool(dev, level, ci, co, T, B):
+    """Encoder layer: SkeletonPool (mean of <= 2 edges) + LeakyReLU folded into the stride-2 convolution (enc0 / enc2 /
+    enc3 shapes): forward gives the pooled activated tensor, backward-data and the deduplicated weight gradient take the
+    gradient w.r.t. the pooled pre-activation, the bias gradient is a scaled row sum of it."""
+    from hm_vae_amd import ops, topology, _lib
+    torch.manual_seed(23 + level)
+    edges = topology.edges_from_parents(topology.SMPL24_PARENTS)
+    for _ in range(level):
+        edges = topology.derive_pooling(edges)[2]
+    pooling = topology.derive_pooling(edges, last_pool=(level == 3))[1]
+    neigh = topology.find_neighbor(edges, 2)
+    n_f, n_p = len(neigh), len(pooling)
+    K, pad = 15, 7
+    cin, cout = n_f * ci, n_f * co
+    mask = O.conv_mask(neigh, cin, cout, K)
+    fan = mask[:, :, 0].sum(1, keepdim=True)[:, :, None] * K
+    w = (torch.randn(cout, cin, K) * mask / fan.sqrt()).requires_grad_(True)
+    b = (0.1 * torch.randn(cout)).requires_grad_(True)
+    x = torch.randn(B, cin, T, requires_grad=True)
+    y = O.skel_conv(x, w, mask, b, 2, pad, "reflect")
+    T_out = y.shape[2]
+    Pm = torch.zeros(n_p * co, cout)
+    for i, grp in enumerate(pooling):
+        for j in grp:
+            for c in range(co):
+                Pm[i * co + c, j * co + c] = 1.0 / len(grp)
+    pre = torch.einsum("pr,brt->bpt", Pm, y)
+    pre.retain_grad()
+    a = F.leaky_relu(pre, 0.2)
+    ga = torch.randn_like(a)
+    a.backward(ga)
+    op = ops.conv_gemm(dev, neigh, cin, cout, K, 2, pad, "reflect", T, need_dx=True, pool_groups=pooling)
+    assert op.folded and op.fused_pool and op.wg_pooled_dz
+    wd = w.detach().to(dev)
+    op.pack(wd + (1 - mask.to(dev)) * 3.0)            # poisoned masked-out weights must not leak through merged rows
+    xs, bp = soa_from_bct(x.detach(), dev)
+    As = torch.full((n_p * co * T_out, bp), float("nan"), device=dev)
+    op.forward(xs, As, bp, bias=b.detach().to(dev), flags=_lib.FLAG_LEAKY)
+    assert rel_err(bct_from_soa(As, B, n_p * co, T_out).numpy(), a.detach().numpy()) < TOL
+    dps, _ = soa_from_bct(pre.grad, dev)
+    dxs = torch.full((cin * T, bp), float("nan"), device=dev)
+    op.backward_data(dps, dxs, bp)
+    assert rel_err(bct_from_soa(dxs, B, cin, T).numpy(), x.grad.numpy()) < TOL
+    dw = torch.zeros(cout, cin, K, device=dev)
+    slab = torch.empty(op.slab_floats(bp), device=dev)
+    op.backward_weight(dps, xs, dw, bp, slab)
+    assert rel_err(dw.cpu().numpy(), w.grad.numpy()) < TOL
+    assert float((dw.cpu() * (1 - mask)).abs().max()) == 0.0
+    rows = torch.as_tensor(op.pool_dst_base[op.pool_rmap].astype(np.int32)).to(dev)
+    scale = torch.as_tensor(op.pool_scale[op.pool_rmap].astype(np.float32)).to(dev)
+    db = torch.empty(cout, device=dev)
+    ops.row_sums_scaled(dps, db, rows, scale, cout, T_out, 1, bp)
+    assert rel_err(db.cpu().numpy(), b.grad.numpy()) < TOL
+
+
 @pytest.mark.parametrize("B,k_edges,n_in,n_out", [(5, 7, 384, 48), (70, 14, 12, 384), (3, 9, 384, 24)])
 def test_linear_per_edge(dev, B, k_edges, n_in, n_out):
     from hm_vae_amd import ops
