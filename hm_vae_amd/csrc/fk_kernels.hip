@@ -750,93 +750,75 @@ struct ChainLds {                        // phase B policy: rotations come from 
 };
 
 constexpr int TF_FRAMES = 32;
+constexpr int TF_GROUPS = 4;             // groups of 32 frames a workgroup walks; the next group's inputs are in flight
+                                         // (registers) while the current group's outputs stream out
 __global__ __launch_bounds__(256) void decode_tail_fwd_kernel(const float* __restrict__ dec, const float* __restrict__ offs,
                                                               int T, int B, int bp, float* __restrict__ c6,
                                                               float* __restrict__ R, float* __restrict__ P) {
     constexpr int L6 = NJ * 6 + 1, LR = NJ * 9 + 1, LP = NJ * 3 + 1;
+    constexpr int LIFTS = NJ * TF_FRAMES / 256;      // lifts per thread
     __shared__ float s6[TF_FRAMES * L6];
     __shared__ float sR[TF_FRAMES * LR];
     __shared__ float sP[TF_FRAMES * LP];
-    const int b0 = blockIdx.x * TF_FRAMES;
     const int t = blockIdx.y;
-    const int nf = B - b0 < TF_FRAMES ? B - b0 : TF_FRAMES;          // frames of this workgroup
     const size_t rs = (size_t)T * bp;
-    // A: lifts
-    {
-        const int f = threadIdx.x & (TF_FRAMES - 1);
+    const int f = threadIdx.x & (TF_FRAMES - 1);
+    const int j0 = threadIdx.x / TF_FRAMES;
+    float in[LIFTS][6];
+    auto load_inputs = [&](int b0) {                 // coalesced 128-byte row pieces; b0 + f < bp always (bp % 64 == 0)
         const float* x = dec + (size_t)t * bp + b0 + f;
-        if (f < nf) {
 #pragma unroll
-            for (int i = 0; i < (NJ * TF_FRAMES + 255) / 256; ++i) {
-                const int j = (threadIdx.x / TF_FRAMES) + i * (256 / TF_FRAMES);
-                if (j >= NJ) break;
-                float in[6];
+        for (int i = 0; i < LIFTS; ++i) {
+            const int j = j0 + i * (256 / TF_FRAMES);
 #pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    in[k] = x[(size_t)(j * 6 + k) * rs];
-                    s6[f * L6 + j * 6 + k] = in[k];
-                }
-                M3 Rm;
-                lift6d(in, Rm);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) sR[f * LR + j * 9 + k] = Rm.a[k];
-            }
-        }
-    }
-    __syncthreads();
-    // B: chain, one subtree role per wave, lanes 0..31 = frames
-    {
-        const int lane = threadIdx.x & 63;
-        const int role = threadIdx.x >> 6;
-        if (lane < nf) {
-            ChainLds io{offs, sR + lane * LR, sP + lane * LP};
-            M3 G0;
-            io.rot(0, G0);
-            const V3 P0 = io.off(0);        // fk_layer.py:69 -- the root keeps its own offset as position
-            if (role == 1) {
-                fk_fwd_node<1>(G0, P0, io);
-                fk_fwd_node<2>(G0, P0, io);
-            } else {
-                M3 Rm;
-                io.rot(3, Rm);
-                const V3 P3 = P0 + mulv(G0, io.off(3));
-                const M3 G3 = mul(G0, Rm);
-                io.rot(6, Rm);
-                const V3 P6 = P3 + mulv(G3, io.off(6));
-                const M3 G6 = mul(G3, Rm);
-                io.rot(9, Rm);
-                const V3 P9 = P6 + mulv(G6, io.off(9));
-                const M3 G9 = mul(G6, Rm);
-                if (role == 0) {
-                    io.put_P(0, P0);
-                    io.put_P(3, P3);
-                    io.put_P(6, P6);
-                    io.put_P(9, P9);
-                    fk_fwd_node<12>(G9, P9, io);
-                } else if (role == 2) {
-                    fk_fwd_node<13>(G9, P9, io);
-                } else {
-                    fk_fwd_node<14>(G9, P9, io);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // C: out[(b0 + f) * T + t][0..n): n floats per frame, consecutive threads -> consecutive 16-byte pieces
-    auto stream_out = [&](auto n_c, const float* lds, float* out) {
-        constexpr int n = decltype(n_c)::value;        // compile-time: the division below is a multiply
-        // 16-byte stores (a quarter of the store instructions; the four LDS reads per lane are 4-way bank conflicted,
-        // which is cheaper than the extra global stores: 165 vs 182 us at 262 144 frames)
-        for (int i = threadIdx.x; i < nf * (n / 4); i += 256) {
-            const int f = i / (n / 4), q = i - f * (n / 4);
-            const float* l = lds + f * (n + 1) + 4 * q;
-            const float4 v = {l[0], l[1], l[2], l[3]};
-            *(float4*)(out + ((size_t)(b0 + f) * T + t) * n + 4 * q) = v;
+            for (int k = 0; k < 6; ++k) in[i][k] = x[(size_t)(j * 6 + k) * rs];
         }
     };
-    stream_out(std::integral_constant<int, NJ * 6>{}, s6, c6);
-    stream_out(std::integral_constant<int, NJ * 9>{}, sR, R);
-    stream_out(std::integral_constant<int, NJ * 3>{}, sP, P);
+    const int g0 = blockIdx.x * TF_GROUPS;
+    if (g0 * TF_FRAMES < B) load_inputs(g0 * TF_FRAMES);
+    for (int g = g0; g < g0 + TF_GROUPS; ++g) {
+        const int b0 = g * TF_FRAMES;
+        if (b0 >= B) break;
+        const int nf = B - b0 < TF_FRAMES ? B - b0 : TF_FRAMES;      // frames of this group
+        // A: lifts (from the registers loaded one group ahead)
+#pragma unroll
+        for (int i = 0; i < LIFTS; ++i) {
+            const int j = j0 + i * (256 / TF_FRAMES);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s6[f * L6 + j * 6 + k] = in[i][k];
+            M3 Rm;
+            lift6d(in[i], Rm);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) sR[f * LR + j * 9 + k] = Rm.a[k];
+        }
+        __syncthreads();
+        // B: chain, one subtree role per wave, lanes 0..31 = frames
+        {
+            const int lane = threadIdx.x & 63;
+            if (lane < nf) {
+                ChainLds io{offs, sR + lane * LR, sP + lane * LP};
+                fk_chain_role(threadIdx.x >> 6, io);
+            }
+        }
+        __syncthreads();
+        if ((g + 1) < g0 + TF_GROUPS && (g + 1) * TF_FRAMES < B) load_inputs((g + 1) * TF_FRAMES);
+        // C: out[(b0 + f) * T + t][0..n): n floats per frame, consecutive threads -> consecutive 16-byte pieces
+        auto stream_out = [&](auto n_c, const float* lds, float* out) {
+            constexpr int n = decltype(n_c)::value;        // compile-time: the division below is a multiply
+            // 16-byte stores (a quarter of the store instructions; the four LDS reads per lane are 4-way bank conflicted,
+            // which is cheaper than the extra global stores: 165 vs 182 us at 262 144 frames)
+            for (int i = threadIdx.x; i < nf * (n / 4); i += 256) {
+                const int fr = i / (n / 4), q = i - fr * (n / 4);
+                const float* l = lds + fr * (n + 1) + 4 * q;
+                const float4 v = {l[0], l[1], l[2], l[3]};
+                *(float4*)(out + ((size_t)(b0 + fr) * T + t) * n + 4 * q) = v;
+            }
+        };
+        stream_out(std::integral_constant<int, NJ * 6>{}, s6, c6);
+        stream_out(std::integral_constant<int, NJ * 9>{}, sR, R);
+        stream_out(std::integral_constant<int, NJ * 3>{}, sP, P);
+        __syncthreads();                                   // the image is rewritten by the next group
+    }
 }
 
 }  // namespace
@@ -858,7 +840,7 @@ extern "C" int hmvae_decode_tail_fwd(const float* dec_out, const float* offsets,
                                      float* c6, float* R, float* pos, hmvae_stream_t stream) {
     if (!dec_out || !offsets || !c6 || !R || !pos) return HMVAE_ERR_ARG;
     if (T <= 0 || T > 65535 || B <= 0 || bp < B || (bp & 63)) return HMVAE_ERR_ARG;
-    dim3 grid((B + TF_FRAMES - 1) / TF_FRAMES, T), block(256);
+    dim3 grid((B + TF_FRAMES * TF_GROUPS - 1) / (TF_FRAMES * TF_GROUPS), T), block(256);
     hipLaunchKernelGGL(decode_tail_fwd_kernel, grid, block, 0, (hipStream_t)stream, dec_out, offsets, T, B, bp, c6, R, pos);
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }
