@@ -85,7 +85,7 @@ def instrument_gemms(engine, timer, bp):
         for side in (op.fwd, op.bwd):
             if side is None:
                 continue
-            issued = 2.0 * side.g.mfma_cost() * side.g.kt * side.n_pos     # what the MFMAs execute (padding, folding)
+            issued = 2.0 * side.g.mfma_cost() * sum(len(l) for l in side.pairs_host)   # what the MFMAs execute
             restore.append((side, "run", timer.wrap(side, "run", fam, lambda *a, _f=useful_f, _i=issued, **k:
                                                     (_f * a[2], _i * a[2]) if len(a) > 2 else (0.0, 0.0))))
         restore.append((op, "backward_weight", timer.wrap(op, "backward_weight", "wgrad_kernel(+reduce)",

@@ -49,6 +49,31 @@ def all_reduce_mean_(flat):
     return flat
 
 
+def all_reduce_sum_async(flat):
+    """Start an in-place SUM all-reduce; returns the work handle (None when not distributed)."""
+    if not is_distributed():
+        return None
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def all_reduce_sum_(flat):
+    if is_distributed() and flat.numel():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def wait(handle):
+    if handle is not None:
+        handle.wait()
+
+
+def scale_(flat):
+    """sum -> mean over the ranks."""
+    if is_distributed():
+        flat.mul_(1.0 / dist.get_world_size())
+    return flat
+
+
 def broadcast_parameters(params, src=0):
     """Make every rank start from rank `src`'s weights (one coalesced broadcast)."""
     if not is_distributed():

@@ -235,16 +235,19 @@ class VaeEngine:
             return self._flat
         p, L = self.p, self.p.L
         enc_w, enc_b, dconv = self.names()
+        # decoder first: its gradients are complete half-way through the backward pass, so under DDP their slice of the
+        # bucket is all-reduced while the encoder's backward runs (graph_step.py)
         always = []
-        for i in range(L):
-            always += [enc_w[i], enc_b[i]]
-        always += ["enc.latent_enc_layers.%d.%s" % (L - 1, s) for s in ("weight", "bias")]
         for i in range(L):
             always.append(dconv[i] + ".weight")
             if p.dec_bias[i]:
                 always.append(dconv[i] + ".bias")
         for i in (0, L - 1):
             always += ["dec.latent_dec_layers.%d.%s" % (i, s) for s in ("weight", "bias")]
+        n_dec_names = len(always)
+        for i in range(L):
+            always += [enc_w[i], enc_b[i]]
+        always += ["enc.latent_enc_layers.%d.%s" % (L - 1, s) for s in ("weight", "bias")]
         phase2 = ["enc.latent_enc_layers.0.%s" % s for s in ("weight", "bias")]
         never = []
         for i in range(1, L - 1):
@@ -258,6 +261,7 @@ class VaeEngine:
             o = (o + 3) // 4 * 4
         n1 = offs[phase2[0]]
         n2 = offs[never[0]] if never else o
+        self.n_dec_floats = offs[always[n_dec_names]]          # [0, n_dec_floats): every decoder gradient
         self.flat_grad = torch.zeros(o, dtype=torch.float32, device=self.device)
         self._flat = (order, offs, n1, n2, set(always), set(phase2), set(never))
         return self._flat
@@ -388,7 +392,7 @@ class VaeEngine:
     # ------------------------------------------------------------------------------------------
     # the training / validation step
     # ------------------------------------------------------------------------------------------
-    def train_step(self, r6, rmat, iterations, eps_list=None, backward=True, repack=True):
+    def train_step(self, r6, rmat, iterations, eps_list=None, backward=True, repack=True, stage="all"):
         """r6 (B,T,144), rmat (B,T,216): fp32 device tensors.  Returns the `losses` device tensor:
         [total, kl, rec_6d, rec_rot, rec_pose, kl_level0, kl_deep, 0]."""
         hp, p, P = self.hp, self.p, self.params
@@ -437,11 +441,20 @@ class VaeEngine:
                               1.0 / (B * p.edge_num[1]), 1.0 / (B * p.edge_num[L]), hp["rec_6d_w"], hp["rec_rot_w"],
                               hp["rec_pose_w"], hp["kl_w"], hp["shallow_kl_w"], ls)
         if backward:
-            self._backward(w, phase2, eps, B, bp)
-            self.assign_grads(phase2)
+            # stage "dec": stop after the decoder's backward (all its gradients final, side streams joined);
+            # backward_rest() then runs the latent + encoder part.  DDP uses the cut to overlap the first all-reduce.
+            self._bw_ctx = (w, phase2, eps, B, bp)
+            self._backward(w, phase2, eps, B, bp, part="dec" if stage == "dec" else "all")
+            if stage != "dec":
+                self.assign_grads(phase2)
         if self._pack_stream is not None:
             torch.cuda.current_stream().wait_stream(self._pack_stream)
         return ls
+
+    def backward_rest(self):
+        w, phase2, eps, B, bp = self._bw_ctx
+        self._backward(w, phase2, eps, B, bp, part="enc")
+        self.assign_grads(phase2)
 
     # ---- weight / bias gradients run on a side stream ----
     # They only READ dY and the forward activations and write gradient slices nobody else touches, so they overlap
@@ -496,10 +509,19 @@ class VaeEngine:
                 before()
             op.wgrad_gemm(dy, x, bp, slab)
 
-    def _backward(self, w, phase2, eps, B, bp):
+    def _backward(self, w, phase2, eps, B, bp, part="all"):
         hp, p, L = self.hp, self.p, self.p.L
-        self._pending_red, self._pending_rs = [], []
         enc_w, enc_b, dconv = self.names()
+        if part in ("all", "dec"):
+            self._pending_red, self._pending_rs = [], []
+            self._backward_decoder(w, phase2, bp, dconv)
+            if part == "dec":
+                self._join()
+                return
+        self._backward_encoder(w, phase2, eps, B, bp, enc_w, enc_b)
+
+    def _backward_decoder(self, w, phase2, bp, dconv):
+        hp, p, L = self.hp, self.p, self.p.L
         # ---------------- decoder ----------------
         for i in range(L - 1, -1, -1):
             t_conv = p.dec_ts[i + 1]
@@ -540,6 +562,9 @@ class VaeEngine:
         self._wgrad(lin, w["dH0"], w["Z%d" % (L - 1)], "dec.latent_dec_layers.0.weight", bp, w,
                     (w["dH0"], "dec.latent_dec_layers.0.bias", "dlinb0", base, p.dec_feat[0], p.edge_num[L], p.dec_feat[0]))
         lin.backward_data(w["dH0"], w["dZ%d" % (L - 1)], bp)
+
+    def _backward_encoder(self, w, phase2, eps, B, bp, enc_w, enc_b):
+        hp, p, L = self.hp, self.p, self.p.L
         # ---------------- reparametrisation + KL ----------------
         k, d = p.edge_num[L], p.lat_dim[L - 1]
         ops.reparam_kl_bwd(w["ZD%d" % (L - 1)], eps[L - 1], w["dZ%d" % (L - 1)], w["dZD%d" % (L - 1)], k, d, B, bp, True,

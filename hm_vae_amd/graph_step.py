@@ -21,6 +21,12 @@ class GraphedStep:
         self.rmat = data[1].to(device=dev, dtype=torch.float32).contiguous().clone()
         self.data = (self.r6, self.rmat) + tuple(data[2:])
         self.graphs = None
+        self.g1b = None
+        import os
+        # HMVAE_DDP_SPLIT=0: one all-reduce after the whole backward.  HMVAE_FORCE_SPLIT=1: take the multi-graph path
+        # on a single GPU too (tests / overhead measurement).
+        self.split = os.environ.get("HMVAE_DDP_SPLIT", "1") != "0"
+        self.force_split = os.environ.get("HMVAE_FORCE_SPLIT", "0") == "1"
         self._pinned = None
         self.phase2 = None
         self.warmup = warmup
@@ -29,10 +35,17 @@ class GraphedStep:
         self.r6.copy_(data[0], non_blocking=True)
         self.rmat.copy_(data[1], non_blocking=True)
 
-    # -- the step body, split at the collective --
+    # -- the step body, split at the collectives --
     def _fwd_bwd(self):
         eng = self.model.engine()
         self.losses = eng.train_step(self.r6, self.rmat, self.it, eps_list=None, backward=True)
+
+    def _fwd_bwd_dec(self):             # forward + the decoder's backward: every decoder gradient is final afterwards
+        eng = self.model.engine()
+        self.losses = eng.train_step(self.r6, self.rmat, self.it, eps_list=None, backward=True, stage="dec")
+
+    def _bwd_enc(self):
+        self.model.engine().backward_rest()
 
     def _optim(self):
         self.tr.gen_opt.step()
@@ -41,6 +54,19 @@ class GraphedStep:
         if ddp.is_distributed():
             eng = self.model.engine()
             ddp.all_reduce_mean_(eng.flat_grad[:eng.active_grad_floats(self.phase2)])
+
+    def _reduce_dec_async(self):
+        """All-reduce of the decoder's slice of the bucket, asynchronous: RCCL runs it on its own stream once the work
+        queued so far (forward + decoder backward) is done, i.e. beside the encoder's backward."""
+        eng = self.model.engine()
+        return ddp.all_reduce_sum_async(eng.flat_grad[:eng.n_dec_floats])
+
+    def _reduce_enc_and_finish(self, handle):
+        eng = self.model.engine()
+        n = eng.active_grad_floats(self.phase2)
+        ddp.all_reduce_sum_(eng.flat_grad[eng.n_dec_floats:n])
+        ddp.wait(handle)
+        ddp.scale_(eng.flat_grad[:n])
 
     def _capture(self):
         self.phase2 = self.it >= self.cfg['iteration_interval']
@@ -57,9 +83,19 @@ class GraphedStep:
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
         g2 = None
-        if ddp.is_distributed():
-            with torch.cuda.graph(g1):
-                self._fwd_bwd()
+        self.g1b = None
+        if ddp.is_distributed() or self.force_split:
+            if self.split:
+                # three graphs: [forward + decoder backward] -> async all-reduce of the decoder gradients ||
+                # [encoder backward] -> all-reduce of the rest -> [optimiser]
+                with torch.cuda.graph(g1):
+                    self._fwd_bwd_dec()
+                self.g1b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g1b):
+                    self._bwd_enc()
+            else:
+                with torch.cuda.graph(g1):
+                    self._fwd_bwd()
             g2 = torch.cuda.CUDAGraph()
             host_before = dict(self.tr.gen_opt._host_step)
             with torch.cuda.graph(g2):
@@ -91,7 +127,13 @@ class GraphedStep:
         g1, g2 = self.graphs
         g1.replay()
         if g2 is not None:
-            self._reduce()
+            if self.g1b is not None:
+                h = self._reduce_dec_async() if ddp.is_distributed() else None
+                self.g1b.replay()
+                if ddp.is_distributed():
+                    self._reduce_enc_and_finish(h)
+            else:
+                self._reduce()
             g2.replay()
         opt = self.tr.gen_opt
         opt.advance_host_steps(1)

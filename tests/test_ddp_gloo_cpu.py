@@ -74,7 +74,18 @@ def _worker(rank, world, port, tag, phase2, out_dir):
     nfl = eng.active_grad_floats(phase2)
     assert nfl == (n2 if phase2 else n1)
     tail_before = eng.flat_grad[nfl:].clone()
+    # the two-bucket path of graph_step.py (decoder slice asynchronously, then the rest, then one scaling) must give
+    # what the single all-reduce gives
+    two = eng.flat_grad.clone()
+    nd = eng.n_dec_floats
+    assert 0 < nd < nfl and all(offs[nm] < nd for nm in order if nm.startswith("dec.") and nm in always) \
+        and all(offs[nm] >= nd for nm in order if nm.startswith("enc."))
+    h = ddp.all_reduce_sum_async(two[:nd])
+    ddp.all_reduce_sum_(two[nd:nfl])
+    ddp.wait(h)
+    ddp.scale_(two[:nfl])
     ddp.all_reduce_mean_(eng.flat_grad[:nfl])
+    assert torch.allclose(two, eng.flat_grad, rtol=1e-6, atol=0)
     assert torch.equal(eng.flat_grad[nfl:], tail_before)          # tensors without gradient are not communicated
     if rank == 0:
         ref = O.OracleVAE(cfg, seeded, offsets=offsets())

@@ -33,12 +33,12 @@ for name, op in zip(names, convs):
     useful = 2.0 * op.useful_macs_per_col * bp
     gf, gb = op.fwd.g, (op.bwd.g if op.bwd else None)
     t_f = timeit(lambda: op.forward(x, y, bp))
-    issued_f = 2.0 * gf.mfma_cost() * kt * op.fwd.n_pos * bp
+    issued_f = 2.0 * gf.mfma_cost() * sum(len(l) for l in op.fwd.pairs_host) * bp
     line = "%s fwd: tune %s groups %3d pos %2d  %7.1f us %5.1f TF (eff) %5.1f TF issued " % (name, op.fwd.choose(bp), gf.n_groups, op.fwd.n_pos, t_f, useful/t_f/1e6, issued_f/t_f/1e6)
     tot["fwd"] += t_f
     if op.bwd:
         t_b = timeit(lambda: op.backward_data(dy, dx, bp)); tot["bwd"] += t_b
-        issued_b = 2.0 * gb.mfma_cost() * kt * op.bwd.n_pos * bp
+        issued_b = 2.0 * gb.mfma_cost() * sum(len(l) for l in op.bwd.pairs_host) * bp
         line += "| bwd: tune %s groups %3d pos %2d %7.1f us %5.1f TF %5.1f TF issued " % (op.bwd.choose(bp), gb.n_groups, op.bwd.n_pos, t_b, useful/t_b/1e6, issued_b/t_b/1e6)
     t_w = timeit(lambda: op.backward_weight(dy, x, dw, bp, slab)); tot["wg"] += t_w
     line += "| wgrad: tiles %4d split %2d %7.1f us %5.1f TF" % (op.n_tiles, op.n_split(bp), t_w, useful/t_w/1e6)
