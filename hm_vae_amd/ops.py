@@ -533,12 +533,13 @@ class MaskedGemm:
         return P.pick_split(self.n_tiles_t if self.wg_transposed else self.n_tiles, self._k_chunks(bp))
 
     def split_candidates(self, bp):
-        """Splits of the (position, batch) reduction worth timing: the grid is n_tiles * split workgroups of 4 waves and
-        its tail decides (1110 workgroups on 512 slots run 3 rounds, 1024 run 2)."""
-        h, kc = self._split_heuristic(bp), self._k_chunks(bp)
-        cand = sorted(set(max(1, min(c, kc // 2 if kc >= 2 else 1)) for c in
-                          (h, h - 1, h + 1, h + 2, (3 * h + 1) // 2, 2 * h, max(1, h // 2), max(1, (2 * h) // 3))))
-        return [c for c in cand if c <= 2 * h + 1]
+        """Splits of the (position, batch) reduction worth timing.  The grid is n_tiles * split workgroups of 4 waves and
+        its tail decides in a non-monotonic way (measured, tools/wgrad_split_sweep.py: 108 tiles run 57 / 35 / 51 / 41 us
+        at split 1 / 2 / 3 / 4), so the whole small range is timed; the slab (split * tiles * 4 KB * mt) is capped."""
+        kc = self._k_chunks(bp)
+        per = (self.n_tiles_t * self.bwd.g.mt if self.wg_transposed else self.n_tiles * self.wg.mt) * 16 * 64 * 4
+        cand = [c for c in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16) if c <= max(1, kc // 2) and c * per <= (192 << 20)]
+        return cand or [1]
 
     def n_split(self, bp):
         return self._split_tuned.get(bp, self._split_heuristic(bp))
