@@ -51,13 +51,14 @@ class WgradDesc(C.Structure):
     _fields_ = [("dz", _ptr), ("x", _ptr), ("slab", _ptr), ("tile_g", _ptr), ("tile_col0", _ptr), ("g_ncols", _ptr),
                 ("g_choff", _ptr), ("chan_rows", _ptr), ("dz_rows", _ptr), ("n_tiles", _i32), ("n_groups", _i32),
                 ("mt", _i32), ("kt", _i32), ("n_split", _i32), ("t_dst", _i32), ("t_src", _i32), ("stride", _i32),
-                ("pad", _i32), ("pad_mode", _i32), ("bp", _i32), ("dz_ts", _i32), ("x_ts", _i32), ("transposed", _i32)]
+                ("pad", _i32), ("pad_mode", _i32), ("bp", _i32), ("dz_ts", _i32), ("x_ts", _i32), ("transposed", _i32),
+                ("items", _ptr), ("worker_items", _ptr), ("n_workers", _i32), ("pad_", _i32)]
 
 
 class WreduceDesc(C.Structure):
     _fields_ = [("slab", _ptr), ("dense", _ptr), ("tile_g", _ptr), ("tile_col0", _ptr), ("g_ncols", _ptr),
                 ("g_choff", _ptr), ("chan_id", _ptr), ("row_id", _ptr), ("g_nc4", _ptr), ("g_okoff", _ptr), ("pair_ok", _ptr),
-                ("n_tiles", _i32), ("mt", _i32), ("kt", _i32), ("n_split", _i32), ("row_stride", _i32), ("chan_stride", _i32), ("accumulate", _i32), ("child_tab", _ptr), ("child_scale", _ptr), ("child_side", _i32), ("pad_", _i32)]
+                ("n_tiles", _i32), ("mt", _i32), ("kt", _i32), ("n_split", _i32), ("row_stride", _i32), ("chan_stride", _i32), ("accumulate", _i32), ("child_tab", _ptr), ("child_scale", _ptr), ("child_side", _i32), ("pad_", _i32), ("tile_part0", _ptr), ("tile_nparts", _ptr)]
 
 
 class PackOp(C.Structure):

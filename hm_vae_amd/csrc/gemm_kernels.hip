@@ -189,15 +189,44 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
     // LDS: first the per-position activation offset table (during the reduction loop), then the cross-wave sums
     extern __shared__ __attribute__((aligned(16))) float red[];
     unsigned* xtab = (unsigned*)red;                  // [t_dst][64]: byte offset of column c's activation row at position t
-    // XCD-aware work order: XCD x (blockIdx % 8) takes a contiguous range of (tile, split) items, tile-major.  The tiles of
-    // one input block (same activation rows, different output-row pieces) are neighbours in that order, so an XCD's L2
-    // sees ~1/8 of the activations instead of all of them.
-    const int n_items = d.n_tiles * d.n_split;
-    const int per = (n_items + 7) >> 3;
-    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per || item >= n_items) return;
-    const int tile = item / d.n_split;
-    const int sp = item - tile * d.n_split;
+    // Work items = (tile, range of reduction chunks, slab part).  Classic launch: one item per workgroup, item =
+    // (tile, split), XCD x (blockIdx % 8) taking a contiguous tile-major range -- the tiles of one input block (same
+    // activation rows, different output-row pieces) are neighbours, so an XCD's L2 sees ~1/8 of the activations.
+    // Persistent launch (n_workers > 0): exactly (CUs x resident workgroups) workers, each walking a host-made list of
+    // items with the same number of chunks (planner.build_stream_schedule): no tail, fewer tile prologues.
+    int it0, it1;
+    if (d.n_workers > 0) {
+        const int perw = d.n_workers >> 3;
+        const int worker = (blockIdx.x & 7) * perw + (blockIdx.x >> 3);
+        it0 = d.worker_items[2 * worker];
+        it1 = it0 + d.worker_items[2 * worker + 1];
+    } else {
+        const int n_items = d.n_tiles * d.n_split;
+        const int per = (n_items + 7) >> 3;
+        it0 = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if ((int)(blockIdx.x >> 3) >= per || it0 >= n_items) return;
+        it1 = it0 + 1;
+    }
+  for (int item = it0; item < it1; ++item) {
+    int tile, lo, hi;
+    size_t part;
+    {
+        const bool TRq = d.transposed != 0;
+        const int Tq = TRq ? d.t_src + 2 * d.pad : d.t_dst;
+        if (d.n_workers > 0) {
+            tile = d.items[4 * item];
+            lo = d.items[4 * item + 1];
+            hi = d.items[4 * item + 2];
+            part = (size_t)d.items[4 * item + 3];
+        } else {
+            tile = item / d.n_split;
+            const int sp = item - tile * d.n_split;
+            const long long total = (long long)Tq * (d.bp >> 5);
+            lo = (int)(total * sp / d.n_split);
+            hi = (int)(total * (sp + 1) / d.n_split);
+            part = (size_t)sp * d.n_tiles + tile;
+        }
+    }
     const int g = d.tile_g[tile];
     const int col0 = d.tile_col0[tile];
     const int lane = threadIdx.x & 63;
@@ -264,10 +293,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
     // [b0 + 8kk, b0 + 8kk + 8) of its row, so the 4 kk-lanes of a row cover one full 128-byte line, and MFMA k-step j
     // (0..7) uses batch element 8kk + j on both operands.  Chunks are numbered with t fastest, so the four waves of
     // a workgroup work on neighbouring positions of the same batch block at the same time.
-    const int nb32 = bp >> 5;
-    const long long total = (long long)T * nb32;
-    const int lo = (int)(total * sp / d.n_split);
-    const int hi = (int)(total * (sp + 1) / d.n_split);
     const char* __restrict__ dzb = (const char*)(TR ? d.x : d.dz);       // row operand
     const char* __restrict__ xb = (const char*)(TR ? d.dz : d.x);        // column operand
     const unsigned dz_tstep = (unsigned)(TR ? d.x_ts : d.dz_ts) * (unsigned)bp * 4u;
@@ -364,7 +389,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
     __syncthreads();
     const int rl = threadIdx.x >> 4;
     const int cq = threadIdx.x & 15;
-    float* out = d.slab + ((size_t)sp * d.n_tiles + tile) * (MT * 16 * 64);
+    float* out = d.slab + part * (MT * 16 * 64);
 #pragma unroll
     for (int ps = 0; ps < MT; ++ps) {
         const int row = ps * 16 + rl;
@@ -373,6 +398,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
         for (int w = 1; w < 4; ++w) s += *(const f32x4*)(red + w * (MT * 16 * 64) + row * 64 + (cq << 2));
         *(f32x4*)(out + row * 64 + (cq << 2)) = s;
     }
+    __syncthreads();                        // the next item rebuilds the position table in the same LDS
+  }
 }
 
 template <int MT>
@@ -391,8 +418,10 @@ extern "C" int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t str
     if (!desc || !desc->dz || !desc->x || !desc->slab) return HMVAE_ERR_ARG;
     if (desc->bp <= 0 || (desc->bp & 63) || desc->n_tiles <= 0 || desc->n_split <= 0 || desc->kt <= 0) return HMVAE_ERR_ARG;
     if (desc->pad_mode == HMVAE_PAD_REFLECT && desc->pad >= desc->t_src && desc->pad > 0) return HMVAE_ERR_ARG;
-    const long long nblk = (long long)desc->n_tiles * desc->n_split;
+    const long long nblk = desc->n_workers > 0 ? desc->n_workers : (long long)desc->n_tiles * desc->n_split;
     if (nblk > 0x7fffffffLL) return HMVAE_ERR_ARG;
+    if (desc->n_workers < 0 || (desc->n_workers & 7) || (desc->n_workers > 0 && (!desc->items || !desc->worker_items)))
+        return HMVAE_ERR_ARG;
     if (desc->transposed && (desc->stride != 1 || desc->pad_mode != HMVAE_PAD_REFLECT)) return HMVAE_ERR_UNSUPPORTED;
     {
         const int npos = desc->transposed ? desc->t_src + 2 * desc->pad : desc->t_dst;
@@ -438,7 +467,13 @@ __device__ __forceinline__ void wreduce_body(const hmvae_wreduce_desc& d, int bl
             const int rid = d.row_id[g * rows + row];
             if (rid < 0 || !okp[row * ok_stride]) continue;
             float s = 0.f;
-            for (int sp = 0; sp < d.n_split; ++sp) s += sl[sp * split_stride + row * 64];
+            if (d.tile_part0) {                        // persistent weight-gradient launch: the tile's parts are listed
+                const float* pp = d.slab + (size_t)d.tile_part0[tile] * per_tile + col + row * 64;
+                const int np = d.tile_nparts[tile];
+                for (int sp = 0; sp < np; ++sp) s += pp[(size_t)sp * per_tile];
+            } else {
+                for (int sp = 0; sp < d.n_split; ++sp) s += sl[sp * split_stride + row * 64];
+            }
             if (d.child_tab == nullptr) {
                 float* o = ocol + (size_t)rid * d.row_stride;
                 if (d.accumulate) s += *o;

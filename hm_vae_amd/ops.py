@@ -19,7 +19,8 @@ import os as _os
 USE_V2 = _os.environ.get("HMVAE_GEMM", "v2") != "v1"
 AUTOTUNE = _os.environ.get("HMVAE_AUTOTUNE", "1") != "0"
 FOLD = _os.environ.get("HMVAE_FOLD", "1") != "0"        # tap folding for convolutions over fewer positions than taps
-USE_V3 = _os.environ.get("HMVAE_V3", "1") != "0"        # let the autotuner consider the v3 window kernel
+USE_V3 = _os.environ.get("HMVAE_V3", "1") != "0"
+WGRAD_PERSISTENT = _os.environ.get("HMVAE_WGRAD_PERSISTENT", "1") != "0"   # let the autotuner consider the persistent launch        # let the autotuner consider the v3 window kernel
 # optional JSON file that persists the autotuner's choices between processes (profiling runs reuse it so the trace
 # holds only the launches of the timed steps)
 TUNE_CACHE = _os.environ.get("HMVAE_TUNE_CACHE")
@@ -476,6 +477,7 @@ class MaskedGemm:
         # weight-gradient orientation: rows = output channels (standard) or rows = input channels walked over the padded
         # positions (transposed; stride-1 reflect convs only).  Pick the one that issues fewer MFMAs.
         self.wg_transposed = False
+        self._wg_sched = {}
         self._split_tuned = {}
         self._ev_f = self._ev_b = None
         ge = self.geom
@@ -542,12 +544,45 @@ class MaskedGemm:
         return cand or [1]
 
     def n_split(self, bp):
-        return self._split_tuned.get(bp, self._split_heuristic(bp))
+        v = self._split_tuned.get(bp, self._split_heuristic(bp))
+        return 1 if v == "p" else v
+
+    def persistent(self, bp):
+        return self._split_tuned.get(bp) == "p"
+
+    def wg_schedule(self, bp):
+        """Persistent weight-gradient launch: (CUs x resident workgroups) workers with equal numbers of reduction chunks
+        (planner.build_stream_schedule over the tiles), as device tables."""
+        if bp in self._wg_sched:
+            return self._wg_sched[bp]
+        n_tiles = self.n_tiles_t if self.wg_transposed else self.n_tiles
+        mt = self.bwd.g.mt if self.wg_transposed else self.wg.mt
+        kc = self._k_chunks(bp)
+        n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 256
+        per_cu = 2 if mt <= 3 else 1                  # 256 VGPRs at mt 3: two 4-wave workgroups per CU; 320 at mt 4: one
+        n_workers = max(8, (n_cu * per_cu) // 8 * 8)
+        segs, wseg, _, _ = P.build_stream_schedule([kc] * n_tiles, [1] * n_tiles, n_workers, min_steps=2)
+        items = np.zeros((max(len(segs), 1), 4), dtype=np.int32)
+        part0 = np.zeros(n_tiles, dtype=np.int32)
+        nparts = np.zeros(n_tiles, dtype=np.int32)
+        for i, (u, k0, k1, _) in enumerate(segs):
+            items[i] = (u, k0, k1, i)
+            if nparts[u] == 0:
+                part0[u] = i
+            nparts[u] += 1
+        sc = dict(items=_dev(items.reshape(-1), self.device), worker_items=_dev(wseg.astype(np.int32).reshape(-1), self.device),
+                  n_workers=n_workers, n_parts=len(segs), part0=_dev(part0, self.device), nparts=_dev(nparts, self.device))
+        self._wg_sched[bp] = sc
+        return sc
 
     def slab_floats(self, bp):
         """Slab size for the largest split the autotuner may pick."""
-        per = self.n_tiles_t * self.bwd.g.mt * 16 * 64 if self.wg_transposed else self.n_tiles * self.wg.mt * 16 * 64
-        return max(self.split_candidates(bp)) * per
+        n_tiles = self.n_tiles_t if self.wg_transposed else self.n_tiles
+        mt = self.bwd.g.mt if self.wg_transposed else self.wg.mt
+        per = n_tiles * mt * 16 * 64
+        n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 256
+        parts_p = n_tiles + 2 * n_cu + 8              # upper bound of the persistent schedule's parts
+        return max(max(self.split_candidates(bp)) * per, parts_p * mt * 16 * 64)
 
     def autotune_split(self, dy, x, dw, bp, slab):
         if bp in self._split_tuned or not AUTOTUNE or torch.cuda.is_current_stream_capturing():
@@ -556,12 +591,15 @@ class MaskedGemm:
                                              self._k_chunks(bp), int(self.wg_transposed), bp)
         hit = _tune_cache_get(ck)
         if hit is not None:
-            self._split_tuned[bp] = int(hit[0])
+            self._split_tuned[bp] = "p" if hit[0] == "p" else int(hit[0])
             return
         scratch = torch.empty_like(dw)
         best = None
         torch.cuda.synchronize()                 # nothing else on the GPU while the candidates are timed
-        for c in self.split_candidates(bp):
+        cands = list(self.split_candidates(bp))
+        if WGRAD_PERSISTENT and self._k_chunks(bp) >= 8:
+            cands.append("p")
+        for c in cands:
             self._split_tuned[bp] = c
 
             def once():
@@ -590,7 +628,7 @@ class MaskedGemm:
             return _lib.WreduceDesc(_lib.ptr(slab), _lib.ptr(dw), _lib.ptr(self.tile_g_t), _lib.ptr(self.tile_col0_t),
                                     _lib.ptr(self.g_ncols_t), _lib.ptr(b.g_choff), _lib.ptr(b.chan_id), _lib.ptr(b.row_id),
                                     _lib.ptr(b.g_nc4), _lib.ptr(b.g_okoff), _lib.ptr(b.pair_ok), self.n_tiles_t, g.mt, g.kt,
-                                    ns, kt, n_chan * kt, 1 if accumulate else 0)
+                                    ns, kt, n_chan * kt, 1 if accumulate else 0, None, None, 0, 0, *self._wg_parts(bp))
         g, tb = self.wg, self.wg_tabs
         return _lib.WreduceDesc(_lib.ptr(slab), _lib.ptr(dw), _lib.ptr(self.tile_g), _lib.ptr(self.tile_col0),
                                 _lib.ptr(self.g_ncols), _lib.ptr(tb["g_choff"]), _lib.ptr(tb["chan_id"]),
@@ -599,7 +637,7 @@ class MaskedGemm:
                                 1 if accumulate else 0,
                                 None if self.wg_child is None else _lib.ptr(self.wg_child[0]),
                                 None if self.wg_child is None or self.wg_child[2] is None else _lib.ptr(self.wg_child[2]),
-                                0 if self.wg_child is None else self.wg_child[1], 0)
+                                0 if self.wg_child is None else self.wg_child[1], 0, *self._wg_parts(bp))
 
     def reduce_rows(self):
         return (self.bwd.g.mt if self.wg_transposed else self.wg.mt) * 16
@@ -621,8 +659,20 @@ class MaskedGemm:
         d = _lib.WgradDesc(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(slab), _lib.ptr(self.tile_g), _lib.ptr(self.tile_col0),
                            _lib.ptr(self.g_ncols), _lib.ptr(tb["g_choff"]), _lib.ptr(self.wg_chan_rows),
                            _lib.ptr(self.dz_rows), self.n_tiles, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"],
-                           ge["stride"], ge["pad"], ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 0)
+                           ge["stride"], ge["pad"], ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 0, *self._wg_items(bp))
         _lib.check(lib.hmvae_wgrad_gemm(C.byref(d), _lib.stream()), "wgrad_gemm")
+
+    def _wg_items(self, bp):
+        if not self.persistent(bp):
+            return (None, None, 0, 0)
+        sc = self.wg_schedule(bp)
+        return (_lib.ptr(sc["items"]), _lib.ptr(sc["worker_items"]), sc["n_workers"], 0)
+
+    def _wg_parts(self, bp):
+        if not self.persistent(bp):
+            return (None, None)
+        sc = self.wg_schedule(bp)
+        return (_lib.ptr(sc["part0"]), _lib.ptr(sc["nparts"]))
 
 
 def _mg_wgrad_gemm_t(self, dy, x, bp, slab):
@@ -636,7 +686,7 @@ def _mg_wgrad_gemm_t(self, dy, x, bp, slab):
     d = _lib.WgradDesc(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(slab), _lib.ptr(self.tile_g_t), _lib.ptr(self.tile_col0_t),
                        _lib.ptr(self.g_ncols_t), _lib.ptr(b.g_choff), _lib.ptr(b.chan_rows), _lib.ptr(b.dst_rows),
                        self.n_tiles_t, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"], ge["stride"], ge["pad"],
-                       ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 1)
+                       ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 1, *self._wg_items(bp))
     _lib.check(lib.hmvae_wgrad_gemm(C.byref(d), _lib.stream()), "wgrad_gemm(T)")
 
 

@@ -176,6 +176,14 @@ typedef struct {
                                 then dz_rows holds x row bases and chan_rows holds dz row bases.  Same FLOPs per useful
                                 weight, but the 16-row MFMA tiles are filled by the many input channels instead of the
                                 few (6..12) output channels of a joint. */
+    /* Persistent launch (n_workers > 0, a multiple of 8): worker w runs the items worker_items[2w] .. +worker_items[2w+1];
+     * items[i] = {tile, first chunk, end chunk, slab part}: chunks are (position, 32 batch columns) steps of the tile's
+     * reduction, numbered position-fastest; the tile's result is the sum of its parts (hmvae_wreduce_desc.tile_part0 /
+     * tile_nparts).  planner.build_stream_schedule gives every worker the same number of chunks.  n_workers == 0: one
+     * workgroup per (tile, split) as described above. */
+    const int32_t* items;
+    const int32_t* worker_items;
+    int32_t n_workers, pad_;
 } hmvae_wgrad_desc;
 
 int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream);
@@ -204,6 +212,8 @@ typedef struct {
     const int32_t* child_tab;
     const float* child_scale;
     int32_t child_side, pad_;
+    const int32_t* tile_part0;  /* NULL: slab[s][tile], s < n_split.  Else the parts of tile t are slab[tile_part0[t] + i], */
+    const int32_t* tile_nparts; /* i < tile_nparts[t] (persistent weight-gradient launch) */
 } hmvae_wreduce_desc;
 
 int hmvae_wgrad_reduce(const hmvae_wreduce_desc* desc, hmvae_stream_t stream);
