@@ -471,6 +471,154 @@ class OracleVAE:
                     z_dist=zs, dec_out=dec_out, c6=c6, R=R, pos=pos, gt_pos=gt_pos)
 
 
+# --------------------------------------------------------------------------------------
+# TrajectoryModel (trajectory_pred_model.py:45-115, 176-265, 283-305) — SURVEY.md §8 row f-1
+# --------------------------------------------------------------------------------------
+class TrajPlan:
+    """Static structure of TrajectoryModel's encoder (trajectory_pred_model.py:45-104): stride-1 convs, T constant."""
+
+    def __init__(self, hp, parents=SMPL24_PARENTS):
+        L = hp["num_layers"]
+        self.hp, self.L, self.T = hp, L, hp["train_seq_len"]
+        self.K = hp["kernel_size"]
+        self.pad = (self.K - 1) // 2
+        self.pad_mode = _pad_mode(hp["padding_mode"])
+        c0 = 3 if hp["trajectory_input_joint_pos"] else 6                      # :50-53
+        self.ch_base = [c0 * (2 ** i) for i in range(L + 1)]
+        self.topo = [skeleton_edges(parents)]
+        self.neigh, self.pooling, self.edge_num = [], [], [len(self.topo[0])]
+        self.enc_cin, self.enc_cout = [], []
+        for i in range(L):
+            self.neigh.append(edge_neighbours(self.topo[i], hp["skeleton_dist"]))
+            self.enc_cin.append(self.ch_base[i] * self.edge_num[i])
+            self.enc_cout.append(self.ch_base[i + 1] * self.edge_num[i])
+            _, pl, ne = pool_plan(self.topo[i], last_pool=(i == L - 1))
+            self.pooling.append(pl)
+            self.topo.append(ne)
+            self.edge_num.append(len(pl))
+        self.d_model = self.ch_base[-1]
+        self.k_edges = self.edge_num[L]
+        self.fc_in = self.d_model * 7                                          # :192 hard-codes 7 coarse edges
+
+
+def traj_param_shapes(plan):
+    out = {}
+    for i in range(plan.L):
+        out["enc.layers.%d.0.weight" % i] = (plan.enc_cout[i], plan.enc_cin[i], plan.K)
+        out["enc.layers.%d.0.bias" % i] = (plan.enc_cout[i],)
+    out["fc_mapping.weight"] = (3, plan.fc_in)
+    out["fc_mapping.bias"] = (3,)
+    return out
+
+
+def traj_masks(plan):
+    return {"enc.layers.%d.0.mask" % i: conv_mask(plan.neigh[i], plan.enc_cin[i], plan.enc_cout[i], plan.K)
+            for i in range(plan.L)}
+
+
+def traj_name_seeded_params(plan):
+    """Same recipe as `name_seeded_params`, keyed "traj:" + name so the two models do not share draws."""
+    params, masks = {}, traj_masks(plan)
+    for name, shape in traj_param_shapes(plan).items():
+        rng = np.random.default_rng(zlib.crc32(("traj:" + name).encode()))
+        v = rng.standard_normal(shape).astype(np.float32)
+        if name.endswith("bias"):
+            v *= 0.05
+        elif len(shape) == 3:
+            m = masks[name.replace("weight", "mask")].numpy()
+            fan = m[:, :, 0].sum(axis=1, keepdims=True)[:, :, None] * shape[2]
+            v = v * m * np.sqrt(2.0 / np.maximum(fan, 1.0)).astype(np.float32)
+        else:
+            v *= np.float32(math.sqrt(2.0 / shape[1]))
+        params[name] = torch.from_numpy(np.ascontiguousarray(v.astype(np.float32)))
+    return params
+
+
+class OracleTrajectory:
+    """Functional restatement of TrajectoryModel (trajectory_pred_model.py:176-265).
+
+    std_root: the three de-standardisation factors `std_vals[0, 576:579]` (:283-290; the mean cancels in the loss).
+    """
+
+    def __init__(self, hp, params, mean_root, std_root, parents=SMPL24_PARENTS):
+        self.hp = hp
+        self.plan = p = TrajPlan(hp, parents)
+        self.masks = traj_masks(p)
+        self.pool_w = [pool_matrix(p.pooling[i], p.edge_num[i], p.enc_cout[i] // p.edge_num[i]) for i in range(p.L)]
+        self.mean_root = torch.as_tensor(mean_root, dtype=torch.float32).reshape(1, 1, 3)
+        self.std_root = torch.as_tensor(std_root, dtype=torch.float32).reshape(1, 1, 3)
+        shapes = traj_param_shapes(p)
+        self.params = {k: v.detach().clone().float().requires_grad_(True) for k, v in params.items() if k in shapes}
+
+    def trainable(self):
+        return [(n, self.params[n]) for n in traj_param_shapes(self.plan)]
+
+    def encode(self, x):
+        """Encoder.forward (:106-113): conv -> SkeletonPool(mean) -> LeakyReLU(0.2), four times, stride 1."""
+        p, P = self.plan, self.params
+        for i in range(p.L):
+            x = skel_conv(x, P["enc.layers.%d.0.weight" % i], self.masks["enc.layers.%d.0.mask" % i],
+                          P["enc.layers.%d.0.bias" % i], 1, p.pad, p.pad_mode)
+            x = F.leaky_relu(torch.matmul(self.pool_w[i], x), 0.2)
+        return x
+
+    def root_velocity(self, joint_pos):
+        """:220-235 — (B,T,72) normalised joint positions -> (B,T,3) normalised root velocity."""
+        p = self.plan
+        b, T, _ = joint_pos.shape
+        latent = self.encode(joint_pos.float().transpose(1, 2))
+        k = latent.shape[1] // p.d_model
+        feat = latent.reshape(b, k, p.d_model, T).transpose(2, 3).transpose(1, 2).reshape(b, T, -1)
+        return F.linear(feat, self.params["fc_mapping.weight"], self.params["fc_mapping.bias"])
+
+    def trajectory(self, pose, root_v):
+        """gen_motion_w_trajectory (:292-305): pose (T,B,24,3), root_v (T,B,3) normalised.  Frame t >= 1 is moved by
+        the running sum of the de-standardised velocities of frames 1..t; frame 0 stays."""
+        v = self.mean_root + self.std_root * root_v
+        out = [pose[0]]
+        acc = torch.zeros_like(v[0])
+        for t in range(1, pose.shape[0]):
+            acc = acc + v[t]
+            out.append(pose[t] + acc[:, None, :])
+        return torch.stack(out, dim=0)
+
+    def train_forward(self, data, backward=True):
+        """:196-265.  data = the 7-tuple of the loader; uses rot_pos [2], joint_pos [3], root_v [6]."""
+        hp = self.hp
+        rot_pos, joint_pos, root_v = data[2].float(), data[3].float(), data[6].float()
+        b, T, _ = joint_pos.shape
+        out_v = self.root_velocity(joint_pos)
+        l_v = ((out_v - root_v) ** 2).mean()
+        if hp["use_accumulation_root_v"]:
+            pose = rot_pos.reshape(b, T, 24, 3).transpose(0, 1)
+            pred = self.trajectory(pose, out_v.transpose(0, 1))
+            gt = self.trajectory(pose, root_v.transpose(0, 1))
+            l_t = ((pred - gt) ** 2).mean()
+        else:
+            pred = gt = None
+            l_t = torch.zeros(())
+        total = hp["rec_root_v_w"] * l_v + hp["rec_root_trans_w"] * l_t
+        if backward:
+            for t in self.params.values():
+                t.grad = None
+            total.backward()
+        return dict(total=total, rec_root_v=l_v, rec_root_trans=l_t, root_v_out=out_v, pred_traj=pred, gt_traj=gt)
+
+
+def synthetic_traj_batch(b, T, seed=0, nj=24):
+    """Loader-shaped 7-tuple for TrajectoryModel: normalised joint positions / root velocity ~ N(0,1), un-normalised
+    root-relative pose ~ 0.3*N(0,1) with the root at the origin."""
+    g = torch.Generator().manual_seed(seed)
+    joint_pos = torch.randn(b, T, nj * 3, generator=g)
+    rot_pos = 0.3 * torch.randn(b, T, nj, 3, generator=g)
+    rot_pos[:, :, 0] = 0.0
+    root_v = torch.randn(b, T, 3, generator=g)
+    z144 = torch.zeros(b, T, nj * 6)
+    z216 = torch.zeros(b, T, nj * 9)
+    z72 = torch.zeros(b, T, nj * 3)
+    return (z144, z216, rot_pos.reshape(b, T, nj * 3), joint_pos, z72, z72.clone(), root_v)
+
+
 def make_adam(oracle, hp):
     """trainer_motion_vae.py:29-33 — Adam over requires_grad params + StepLR."""
     opt = torch.optim.Adam([t for _, t in oracle.trainable()], lr=hp["lr"], weight_decay=hp["weight_decay"])

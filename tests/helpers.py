@@ -44,3 +44,24 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def load_traj_cfg(T=None):
+    with open(os.path.join(CONFIGS, "trajectory_model.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    if T is not None:
+        cfg["train_seq_len"] = T
+    return cfg
+
+
+def load_traj_golden(tag):
+    g = np.load(os.path.join(GOLDEN, "traj_%s.npz" % tag))
+    meta = json.load(open(os.path.join(GOLDEN, "traj_meta.json")))[tag]
+    return g, meta
+
+
+def traj_batch(g):
+    jp = torch.from_numpy(g["in_joint_pos"])
+    b, T, _ = jp.shape
+    z = lambda n: torch.zeros(b, T, n)
+    return (z(144), z(216), torch.from_numpy(g["in_rot_pos"]), jp, z(72), z(72), torch.from_numpy(g["in_root_v"]))

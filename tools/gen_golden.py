@@ -215,12 +215,78 @@ def model_golden(cfg_name, B, seed):
     return store, meta
 
 
-def main():
-    H.install()
+def traj_golden(B, T, seed):
+    """TrajectoryModel (trajectory_pred_model.py): forward, losses, gradients, two Trainer.gen_update steps."""
+    import trainer_motion_vae as RT
+    cfg = yaml.safe_load(open(os.path.join(H.REF_ROOT, "configs", "trajectory_model.yaml")))
+    cfg["train_seq_len"] = T
+    plan = O.TrajPlan(cfg)
+    tr = RT.Trainer(cfg)
+    model = tr.model
+    seeded = O.traj_name_seeded_params(plan)
+    sd = model.state_dict()
+    for k, v in seeded.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
+        if v.dim() == 3:
+            mk = k.replace("weight", "mask")
+            assert torch.equal((sd[mk] == 0), (v == 0) | (sd[mk] == 0))
+        sd[k] = v.clone()
+    model.load_state_dict(sd)
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    meta = {"cfg": "trajectory_model.yaml", "B": B, "T": T, "state_dict_keys": list(sd.keys()),
+            "trainable_order": [n for n, _ in named], "all_param_order": [n for n, _ in model.named_parameters()]}
+    store = {}
+    trainable_names = set(n for n, _ in named)
+    for k, v in sd.items():
+        if k not in trainable_names:
+            store["const|" + k + "|sum"] = np.float64(v.double().sum().item())
+            store["const|" + k + "|wsum"] = np.float64(
+                (v.double().reshape(-1) * torch.arange(1, v.numel() + 1).double() % 7.0).sum().item())
+    store["mean_root"] = model.mean_vals[0, 576:579].numpy().copy()
+    store["std_root"] = model.std_vals[0, 576:579].numpy().copy()
+    data = O.synthetic_traj_batch(B, T, seed=seed)
+    store["in_rot_pos"], store["in_joint_pos"], store["in_root_v"] = data[2].numpy(), data[3].numpy(), data[6].numpy()
+    caps = {}
+    hooks = [model.enc.register_forward_hook(lambda m, i, o: caps.__setitem__("latent", o)),
+             model.fc_mapping.register_forward_hook(lambda m, i, o: caps.__setitem__("root_v_out", o))]
+    for li, layer in enumerate(model.enc.layers):
+        hooks.append(layer.register_forward_hook(lambda m, i, o, li=li: caps.__setitem__("act%d" % li, o)))
+    tr.gen_opt.zero_grad()
+    ret = model(data, cfg, 0)
+    for h in hooks:
+        h.remove()
+    store["ret"] = np.array([float(x) for x in ret], dtype=np.float64)
+    store["root_v_out"] = caps["root_v_out"].detach().numpy()
+    for li in range(cfg["num_layers"]):
+        a = caps["act%d" % li].detach().reshape(-1).numpy()
+        idx = sample_idx("act%d" % li, a.size, n=2048)
+        store["act%d|idx" % li], store["act%d|val" % li] = idx, a[idx].copy()
+        store["act%d|norm" % li] = np.float64(np.linalg.norm(a.astype(np.float64)))
+    meta["none_grad"] = summarize_grads(named, store, "grad|")
+    with torch.no_grad():
+        gt, pred, _, _ = model.test(data, cfg, 0)
+    store["test_gt"], store["test_pred"] = gt.numpy(), pred.numpy()
+    tr2 = RT.Trainer(cfg)
+    tr2.model.load_state_dict(sd)
+    steps = []
+    for s in range(2):
+        steps.append([float(x) for x in tr2.gen_update(data, cfg, s, False)])
+    store["upd|returns"] = np.array(steps, dtype=np.float64)
+    for n, p in tr2.model.named_parameters():
+        if not p.requires_grad:
+            continue
+        v = p.detach().reshape(-1).numpy()
+        idx = sample_idx("upd:" + n, v.size)
+        store["upd|" + n + "|idx"] = idx
+        store["upd|" + n + "|val"] = v[idx].copy()
+        store["upd|" + n + "|delta"] = (v[idx].astype(np.float64) - seeded[n].reshape(-1).numpy()[idx].astype(np.float64))
+    return store, meta
+
+
+def vae_fixtures():
     import skeleton as ref_skel
     import my_tools as ref_tools
     import fk_layer as ref_fk_mod
-    os.makedirs(OUT, exist_ok=True)
     topo = topology_dump(ref_skel, os.path.join(H.REF_ROOT, "utils/data/joint24_parents.json"))
     json.dump(topo, open(os.path.join(OUT, "topology.json"), "w"))
     np.savez_compressed(os.path.join(OUT, "fk_rot6d.npz"), **fk_rot_golden(ref_tools, ref_fk_mod))
@@ -230,6 +296,20 @@ def main():
         np.savez_compressed(os.path.join(OUT, "model_%s.npz" % tag), **store)
         metas[tag] = meta
     json.dump(metas, open(os.path.join(OUT, "model_meta.json"), "w"), indent=1)
+
+
+def main():
+    only_traj = "--traj-only" in sys.argv
+    H.install()
+    os.makedirs(OUT, exist_ok=True)
+    if not only_traj:
+        vae_fixtures()
+    tmetas = {}
+    for tag, B, T, seed in (("len128", 2, 128, 31), ("len40", 3, 40, 41)):
+        store, meta = traj_golden(B, T, seed)
+        np.savez_compressed(os.path.join(OUT, "traj_%s.npz" % tag), **store)
+        tmetas[tag] = meta
+    json.dump(tmetas, open(os.path.join(OUT, "traj_meta.json"), "w"), indent=1)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
