@@ -113,6 +113,8 @@ _SIGS = {
     "hmvae_decode_tail_fwd": ([_ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr, _ptr, _ptr], _i32),
     "hmvae_vae_loss_finalize": ([_ptr, _i32, _ptr, _i32, _ptr, _i32] + [_f32] * 10 + [_ptr, _ptr], _i32),
     "hmvae_finalize_sums": ([_ptr, _i32, _i32, _i32, _f32, _ptr, _ptr], _i32),
+    "hmvae_traj_loss": ([_ptr, _ptr, _ptr, _i32, _i32, _i32, _f32, _f32, _ptr, _ptr, _ptr, _ptr], _i32),
+    "hmvae_traj_loss_finalize": ([_ptr, _i32, _f32, _f32, _f32, _ptr, _ptr], _i32),
     "hmvae_adam_step": ([_ptr, _i32, _i64, _ptr, _ptr, _f32, _f32, _f32, _f32, _ptr], _i32),
 }
 

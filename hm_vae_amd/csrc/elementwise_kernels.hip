@@ -490,6 +490,93 @@ extern "C" int hmvae_vae_loss_finalize(const float* mse_partial, int32_t n_mse, 
     return LAUNCH_OK();
 }
 
+// ---------------- TrajectoryModel losses (trajectory_pred_model.py:237-262, 292-305) ----------------
+// One thread per (component c, sequence b): d[t] = v[t] - g[t] (normalised root velocity); the trajectory term compares
+// running sums of the de-standardised velocities from frame 1 on (the mean and the pose cancel in pred - gt; all 24
+// joints carry the same offset, so the mean over (T,B,24,3) equals the mean over (T,B,3)):
+//     D[t] = std_c * sum_{1<=s<=t} d[s],  D[0] = 0
+//     L_v = sum d^2 / (3TB),  L_t = sum D^2 / (3TB)
+//     dL/dv[t] = gv * d[t] + (t >= 1) * gt * std_c * sum_{t'>=t} D[t']        gv = 2 w_v/(3TB), gt = 2 w_t/(3TB)
+// Pass 1 parks D in dv, pass 2 walks back with the suffix sum.  Rows: c*T + t, batch innermost (SoA).
+__global__ __launch_bounds__(64) void traj_loss_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                        const float* __restrict__ std3, int T, int B, int bp, float gv,
+                                                        float gt, float* __restrict__ dv, float* __restrict__ partial) {
+    const int chunks = bp >> 6;
+    const int c = blockIdx.x / chunks;
+    const int b = (blockIdx.x - c * chunks) * 64 + threadIdx.x;
+    const float sd = std3[c];
+    const size_t base = (size_t)c * T * bp + b;
+    float sv = 0.f, st = 0.f;
+    if (b < B) {
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const size_t o = base + (size_t)t * bp;
+            const float d = v[o] - g[o];
+            sv += d * d;
+            if (t >= 1) acc += sd * d;
+            st += acc * acc;
+            dv[o] = acc;
+        }
+        float suf = 0.f;
+        for (int t = T - 1; t >= 0; --t) {
+            const size_t o = base + (size_t)t * bp;
+            const float d = v[o] - g[o];
+            suf += dv[o];
+            dv[o] = gv * d + (t >= 1 ? gt * sd * suf : 0.f);
+        }
+    } else {
+        for (int t = 0; t < T; ++t) dv[base + (size_t)t * bp] = 0.f;
+    }
+    sv = wave_sum(sv);
+    st = wave_sum(st);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = sv;
+        partial[2 * blockIdx.x + 1] = st;
+    }
+}
+
+extern "C" int hmvae_traj_loss(const float* v, const float* g, const float* std3, int32_t T, int32_t B, int32_t bp,
+                               float grad_v, float grad_t, float* dv, float* partial, int32_t* n_blocks_out,
+                               hmvae_stream_t stream) {
+    if (bp <= 0 || (bp & 63) || B <= 0 || B > bp || T <= 0) return HMVAE_ERR_ARG;
+    const int n_blocks = 3 * (bp >> 6);
+    if (n_blocks_out) *n_blocks_out = n_blocks;
+    if (!v && !g && !dv && !partial) return HMVAE_OK;          // size query
+    if (!v || !g || !std3 || !dv || !partial) return HMVAE_ERR_ARG;
+    hipLaunchKernelGGL(traj_loss_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, v, g, std3, T, B, bp, grad_v,
+                       grad_t, dv, partial);
+    return LAUNCH_OK();
+}
+
+// out = the nine values TrajectoryModel.forward returns (:265): [total, 0, 0, 0, 0, 0, rec_root_v, 0, rec_root_trans]
+__global__ __launch_bounds__(256) void traj_loss_finalize_kernel(const float* __restrict__ partial, int n_blocks,
+                                                                  float inv_n, float wv, float wt, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n_blocks; i += 256) {
+        a += partial[2 * i];
+        b += partial[2 * i + 1];
+    }
+    const float sv = block_sum256(a, sh);
+    const float st = block_sum256(b, sh);
+    if (threadIdx.x < 9) {
+        const float lv = sv * inv_n, lt = st * inv_n;
+        float r = 0.f;
+        if (threadIdx.x == 0) r = wv * lv + wt * lt;
+        if (threadIdx.x == 6) r = lv;
+        if (threadIdx.x == 8) r = lt;
+        out[threadIdx.x] = r;
+    }
+}
+
+extern "C" int hmvae_traj_loss_finalize(const float* partial, int32_t n_blocks, float inv_n, float w_v, float w_t,
+                                        float* out9, hmvae_stream_t stream) {
+    if (!partial || !out9 || n_blocks <= 0) return HMVAE_ERR_ARG;
+    hipLaunchKernelGGL(traj_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n_blocks, inv_n, w_v,
+                       w_t, out9);
+    return LAUNCH_OK();
+}
+
 // ---------------- Adam ----------------
 __global__ __launch_bounds__(256) void adam_kernel(const hmvae_adam_tensor* __restrict__ tab,
                                                     const float* __restrict__ lr_dev, const int* __restrict__ step_dev,

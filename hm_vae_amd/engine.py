@@ -65,7 +65,93 @@ class VaePlan:
         self.dec_feat = [self.ch_base[L - i] * self.dec_ts[i] for i in range(L)]        # Linear out-features, dec idx i
 
 
-class VaeEngine:
+class _StepBase:
+    """What the fixed kernel sequences of both models share: cached index tables, views into the flat gradient bucket,
+    and the side streams the weight-gradient GEMMs run on."""
+
+    def _init_step_base(self, device):
+        import os as _os
+        self.device = device
+        self._bias_rows = {}
+        self._flat = None
+        self._side = None
+        self.overlap = _os.environ.get("HMVAE_OVERLAP", "1") != "0"
+        self.n_side = int(_os.environ.get("HMVAE_SIDE_STREAMS", "2"))
+        self._turn = 0
+        self._pending_red, self._pending_rs = [], []
+
+    def _scales(self, key, scale):
+        k = ("scale", key)
+        if k not in self._bias_rows:
+            self._bias_rows[k] = torch.as_tensor(np.asarray(scale, dtype=np.float32)).to(self.device)
+        return self._bias_rows[k]
+
+    def _rows(self, key, base, count):
+        k = (key, count)
+        if k not in self._bias_rows:
+            self._bias_rows[k] = torch.as_tensor(np.asarray(base, dtype=np.int32)).to(self.device)
+        return self._bias_rows[k]
+
+    def grad_view(self, name):
+        order, offs, *_ = self.grad_layout()
+        t = self.params[name]
+        return self.flat_grad[offs[name]:offs[name] + t.numel()].view(t.shape)
+
+    # ---- weight / bias gradients run on a side stream ----
+    # They only READ dY and the forward activations and write gradient slices nobody else touches, so they overlap
+    # with the backward-data chain of the following layers (two kernels that each leave SIMDs idle in their tails
+    # fill the chip together).  Fork = event on the main stream once dY is final; join = end of _backward.
+    def _fork(self):
+        if not self.overlap:
+            return None
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.n_side)]
+        self._turn = (self._turn + 1) % self.n_side
+        side = self._side[self._turn]
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        return torch.cuda.stream(side)
+
+    def _join(self):
+        if self.overlap and self._side is not None:
+            for s in self._side:
+                torch.cuda.current_stream().wait_stream(s)
+
+    def _wgrad(self, op, dy, x, name, bp, w, bias=None, before=None):
+        """bias: optional (src, grad_name, rows_key, base, n_out, rows_per_out, row_step) for the row-sum kernel.
+        before: launches that produce `x`, issued on the same side stream first."""
+        slab = w["slabs"][id(op)]
+        if not MULTI_REDUCE:
+            # default: GEMM + reduction + bias sums all on the side stream, overlapped with the data-gradient chain
+            ctx = self._fork() or contextlib.nullcontext()
+            with ctx:
+                if before is not None:
+                    before()
+                op.backward_weight(dy, x, self.grad_view(name), bp, slab)
+                if bias is not None:
+                    src, gname, key, base, n_out, rows_per, step = bias[:7]
+                    if len(bias) > 7:       # factor per output: rows averaged by a folded SkeletonPool
+                        ops.row_sums_scaled(src, self.grad_view(gname), self._rows(key, base, len(base)),
+                                            self._scales(key, bias[7]), n_out, rows_per, step, bp)
+                    else:
+                        ops.row_sums(src, self.grad_view(gname), self._rows(key, base, len(base)), n_out, rows_per, step, bp)
+            return
+        self._pending_red.append((op, slab, self.grad_view(name)))
+        if bias is not None:
+            if len(bias) > 7:
+                raise _lib.HmvaeError("HMVAE_MULTI_REDUCE=1 does not support folded pooling (set HMVAE_FOLD=0)")
+            src, gname, key, base, n_out, rows_per, step = bias
+            self._pending_rs.append((src, self.grad_view(gname), self._rows(key, base, len(base)), n_out, rows_per, step))
+        ctx = self._fork() or contextlib.nullcontext()
+        with ctx:
+            if before is not None:
+                before()
+            op.wgrad_gemm(dy, x, bp, slab)
+
+
+class VaeEngine(_StepBase):
     """Owns device tables + workspaces; borrows the parameter tensors from the nn.Modules (dict name -> Parameter)."""
 
     def __init__(self, hp, params, offsets, device, parents=topology.SMPL24_PARENTS):
@@ -129,10 +215,8 @@ class VaeEngine:
                                               self.cat_edge_rows, y_offset=self.cD * t_cat)
         # the dead middle heads (seq_two_hier_sa_vae.py:264-272 computes them, nothing consumes them) exist only for
         # Decoder.forward's API; they are built lazily
+        self._init_step_base(device)
         self._ws = {}
-        self._bias_rows = {}
-        self._flat = None
-        self._side = None
         self._pack_stream = None
         self._multipack = None
         self._multipack_late = None
@@ -140,10 +224,7 @@ class VaeEngine:
         self._early = None
         self._multired = None
         import os as _os
-        self.overlap = _os.environ.get("HMVAE_OVERLAP", "1") != "0"
-        self.n_side = int(_os.environ.get("HMVAE_SIDE_STREAMS", "2"))
         self.pack_async = _os.environ.get("HMVAE_PACK_ASYNC", "0") == "1"
-        self._turn = 0
         self.flops_per_seq = self._count_flops()
 
     # ------------------------------------------------------------------------------------------
@@ -153,18 +234,6 @@ class VaeEngine:
         for op in self.enc_conv + self.dec_conv:
             tot += 2 * op.useful_macs_per_col
         return tot
-
-    def _scales(self, key, scale):
-        k = ("scale", key)
-        if k not in self._bias_rows:
-            self._bias_rows[k] = torch.as_tensor(np.asarray(scale, dtype=np.float32)).to(self.device)
-        return self._bias_rows[k]
-
-    def _rows(self, key, base, count):
-        k = (key, count)
-        if k not in self._bias_rows:
-            self._bias_rows[k] = torch.as_tensor(np.asarray(base, dtype=np.int32)).to(self.device)
-        return self._bias_rows[k]
 
     def workspace(self, B):
         if B in self._ws:
@@ -265,11 +334,6 @@ class VaeEngine:
         self.flat_grad = torch.zeros(o, dtype=torch.float32, device=self.device)
         self._flat = (order, offs, n1, n2, set(always), set(phase2), set(never))
         return self._flat
-
-    def grad_view(self, name):
-        order, offs, *_ = self.grad_layout()
-        t = self.params[name]
-        return self.flat_grad[offs[name]:offs[name] + t.numel()].view(t.shape)
 
     def assign_grads(self, phase2):
         """Point .grad of the live parameters at their slice of the flat bucket; the rest get None
@@ -455,59 +519,6 @@ class VaeEngine:
         w, phase2, eps, B, bp = self._bw_ctx
         self._backward(w, phase2, eps, B, bp, part="enc")
         self.assign_grads(phase2)
-
-    # ---- weight / bias gradients run on a side stream ----
-    # They only READ dY and the forward activations and write gradient slices nobody else touches, so they overlap
-    # with the backward-data chain of the following layers (two kernels that each leave SIMDs idle in their tails
-    # fill the chip together).  Fork = event on the main stream once dY is final; join = end of _backward.
-    def _fork(self):
-        if not self.overlap:
-            return None
-        main = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.n_side)]
-        self._turn = (self._turn + 1) % self.n_side
-        side = self._side[self._turn]
-        ev = torch.cuda.Event()
-        ev.record(main)
-        side.wait_event(ev)
-        return torch.cuda.stream(side)
-
-    def _join(self):
-        if self.overlap and self._side is not None:
-            for s in self._side:
-                torch.cuda.current_stream().wait_stream(s)
-
-    def _wgrad(self, op, dy, x, name, bp, w, bias=None, before=None):
-        """bias: optional (src, grad_name, rows_key, base, n_out, rows_per_out, row_step) for the row-sum kernel.
-        before: launches that produce `x`, issued on the same side stream first."""
-        slab = w["slabs"][id(op)]
-        if not MULTI_REDUCE:
-            # default: GEMM + reduction + bias sums all on the side stream, overlapped with the data-gradient chain
-            ctx = self._fork() or contextlib.nullcontext()
-            with ctx:
-                if before is not None:
-                    before()
-                op.backward_weight(dy, x, self.grad_view(name), bp, slab)
-                if bias is not None:
-                    src, gname, key, base, n_out, rows_per, step = bias[:7]
-                    if len(bias) > 7:       # factor per output: rows averaged by a folded SkeletonPool
-                        ops.row_sums_scaled(src, self.grad_view(gname), self._rows(key, base, len(base)),
-                                            self._scales(key, bias[7]), n_out, rows_per, step, bp)
-                    else:
-                        ops.row_sums(src, self.grad_view(gname), self._rows(key, base, len(base)), n_out, rows_per, step, bp)
-            return
-        self._pending_red.append((op, slab, self.grad_view(name)))
-        if bias is not None:
-            if len(bias) > 7:
-                raise _lib.HmvaeError("HMVAE_MULTI_REDUCE=1 does not support folded pooling (set HMVAE_FOLD=0)")
-            src, gname, key, base, n_out, rows_per, step = bias
-            self._pending_rs.append((src, self.grad_view(gname), self._rows(key, base, len(base)), n_out, rows_per, step))
-        ctx = self._fork() or contextlib.nullcontext()
-        with ctx:
-            if before is not None:
-                before()
-            op.wgrad_gemm(dy, x, bp, slab)
 
     def _backward(self, w, phase2, eps, B, bp, part="all"):
         hp, p, L = self.hp, self.p, self.p.L

@@ -272,9 +272,9 @@ class _Side:
         for cw in (1, 2, 4):
             if g.mt * cw > 4 or int(bp) % (64 * cw):
                 continue
-            for ks in (2, 4, 8):
-                if ks > 1 and float(g.g_nc4.mean()) / ks < 1.0:
-                    continue
+            # K splits with at least one 4-channel step per wave; tiny reductions (a 3-row head's transpose) get one wave
+            ks_all = [ks for ks in (2, 4, 8) if float(g.g_nc4.mean()) / ks >= 1.0] or [1]
+            for ks in ks_all:
                 self.tune = (cw, ks)
                 t = self._time(lambda: self.run_v2(src, scratch, bp, bias, fl, slope))
                 if best is None or t < best[0]:
@@ -927,6 +927,24 @@ def decode_tail_loss(dec, g6, gR, gP, offsets, T, B, bp, s6, sR, sP, ddec, parti
 def decode_tail_fwd(dec, offsets, T, B, bp, c6, R, pos):
     _lib.check(_lib.load().hmvae_decode_tail_fwd(_lib.ptr(dec), _lib.ptr(offsets), T, B, bp, _lib.ptr(c6), _lib.ptr(R),
                                                  _lib.ptr(pos), _lib.stream()), "decode_tail_fwd")
+
+
+def traj_loss_blocks(T, B, bp):
+    nb = C.c_int32(0)
+    _lib.check(_lib.load().hmvae_traj_loss(None, None, None, T, B, bp, 0.0, 0.0, None, None, C.byref(nb), None), "traj_loss")
+    return nb.value
+
+
+def traj_loss(v, g, std3, T, B, bp, grad_v, grad_t, dv, partial):
+    nb = C.c_int32(0)
+    _lib.check(_lib.load().hmvae_traj_loss(_lib.ptr(v), _lib.ptr(g), _lib.ptr(std3), T, B, bp, grad_v, grad_t, _lib.ptr(dv),
+                                           _lib.ptr(partial), C.byref(nb), _lib.stream()), "traj_loss")
+    return nb.value
+
+
+def traj_loss_finalize(partial, n_blocks, inv_n, w_v, w_t, out9):
+    _lib.check(_lib.load().hmvae_traj_loss_finalize(_lib.ptr(partial), n_blocks, inv_n, w_v, w_t, _lib.ptr(out9),
+                                                    _lib.stream()), "traj_loss_finalize")
 
 
 def finalize_sum(partial, n_partial, stride, k, scale, out):

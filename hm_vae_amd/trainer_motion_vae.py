@@ -15,6 +15,7 @@ import torch.nn.init as init
 from . import ddp
 from .optim import HipAdam
 from .seq_two_hier_sa_vae import TwoHierSAVAEModel, get_scheduler
+from .trajectory_pred_model import TrajectoryModel
 from .utils_common import write_loss  # noqa: F401  (re-exported like the reference module does)
 
 _LOSS_NAMES = ("total", "kl", "rec_6d", "rec_rot", "rec_pose", "rec_joint_pos", "rec_root_v", "rec_linear_v",
@@ -27,7 +28,7 @@ class Trainer(nn.Module):
         if cfg['model_name'] == "TwoHierSAVAEModel":
             self.model = TwoHierSAVAEModel(cfg)
         elif cfg['model_name'] == "TrajectoryModel":
-            raise NotImplementedError("TrajectoryModel is the next scope row (SURVEY.md §8 f-1), not built yet")
+            self.model = TrajectoryModel(cfg)
         else:
             raise ValueError("unknown model_name %r" % cfg['model_name'])
         self.cfg = cfg
@@ -45,7 +46,8 @@ class Trainer(nn.Module):
         if not validation_flag:
             self.gen_opt.zero_grad(set_to_none=True)
         out = model(data, hp, iterations, multigpus=multigpus, validation_flag=validation_flag)
-        kl_list = out[9]
+        is_vae = self.cfg['model_name'] == "TwoHierSAVAEModel"
+        kl_list = out[9] if is_vae else []      # TrajectoryModel returns nine values (trainer_motion_vae.py:43-45, 72-74)
         prefix = "loss_val_" if validation_flag else "loss_"
         # the reference takes torch.mean of each (a no-op unless nn.DataParallel gathered one value per replica)
         for name, val in zip(_LOSS_NAMES, out[:9]):
@@ -53,9 +55,14 @@ class Trainer(nn.Module):
         for i, k in enumerate(kl_list):
             setattr(self, "loss_hier_kl_%d" % (i + 1), k if k.numel() == 1 else torch.mean(k))
         if not validation_flag:
-            eng = model.engine()
             if ddp.is_distributed():
-                ddp.all_reduce_mean_(eng.flat_grad[:eng.active_grad_floats(iterations >= hp['iteration_interval'])])
+                if is_vae:
+                    eng = model.engine()
+                    n = eng.active_grad_floats(iterations >= hp['iteration_interval'])
+                else:
+                    eng = model.last_engine
+                    n = eng.active_grad_floats()
+                ddp.all_reduce_mean_(eng.flat_grad[:n])
             self.gen_opt.step()
             if self.gen_scheduler is not None:
                 self.gen_scheduler.step()
@@ -63,6 +70,8 @@ class Trainer(nn.Module):
         eng_losses = getattr(model, "last_losses", None)
         if eng_losses is not None:
             v = eng_losses.tolist()
+            if not is_vae:
+                return tuple(v[:9])
             return (v[0], v[1], v[2], v[3], v[4], 0.0, 0.0, 0.0, 0.0)
         vals = torch.stack([getattr(self, prefix + n).reshape(()) for n in _LOSS_NAMES]).tolist()
         return tuple(vals)

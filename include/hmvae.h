@@ -352,6 +352,17 @@ int hmvae_vae_loss_finalize(const float* mse_partial, int32_t n_mse, const float
                             float inv_rows0, float inv_rowsd, float w6, float wR, float wP, float w_kl, float w_skl,
                             float* out8, hmvae_stream_t stream);
 
+/* TrajectoryModel losses and their gradient (trajectory_pred_model.py:237-262 with gen_motion_w_trajectory :292-305
+ * and l2_criterion :267-271).  v, g: SoA (3*T rows x bp) predicted / ground-truth normalised root velocity; std3: the
+ * three de-standardisation factors std_vals[576:579] (device).  dv = dL/dv with grad_v = 2*rec_root_v_w/(3*T*B),
+ * grad_t = 2*rec_root_trans_w/(3*T*B) (grad_t = 0 when use_accumulation_root_v is off).  partial: [n_blocks][2]
+ * block sums (squared velocity error, squared trajectory error).  All-NULL buffers: only *n_blocks_out is set. */
+int hmvae_traj_loss(const float* v, const float* g, const float* std3, int32_t T, int32_t B, int32_t bp, float grad_v,
+                    float grad_t, float* dv, float* partial, int32_t* n_blocks_out, hmvae_stream_t stream);
+/* out9 = [total, 0, 0, 0, 0, 0, rec_root_v, 0, rec_root_trans] (the return order of trajectory_pred_model.py:265) */
+int hmvae_traj_loss_finalize(const float* partial, int32_t n_blocks, float inv_n, float w_v, float w_t, float* out9,
+                             hmvae_stream_t stream);
+
 /* out[0..n_out) : fixed-order sums of partial[i*stride + k], scaled */
 int hmvae_finalize_sums(const float* partial, int32_t n_partial, int32_t stride, int32_t k, float scale, float* out,
                         hmvae_stream_t stream);

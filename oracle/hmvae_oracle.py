@@ -553,20 +553,45 @@ class OracleTrajectory:
     def trainable(self):
         return [(n, self.params[n]) for n in traj_param_shapes(self.plan)]
 
-    def encode(self, x):
-        """Encoder.forward (:106-113): conv -> SkeletonPool(mean) -> LeakyReLU(0.2), four times, stride 1."""
+    def encode(self, x, branch=None, band=1e-5):
+        """Encoder.forward (:106-113): conv -> SkeletonPool(mean) -> LeakyReLU(0.2), four times, stride 1.
+
+        branch (checker aid for big batches): per layer a bool (B,C,T) tensor, "the implementation under test took the
+        positive side".  LeakyReLU's derivative jumps at 0, so for an input within fp32 rounding of 0 (|x| < band) both
+        sides are valid fp32 evaluations; there -- and only there -- the oracle follows `branch`.  self.n_ambiguous
+        counts those elements."""
         p, P = self.plan, self.params
+        self.n_ambiguous = 0
         for i in range(p.L):
             x = skel_conv(x, P["enc.layers.%d.0.weight" % i], self.masks["enc.layers.%d.0.mask" % i],
                           P["enc.layers.%d.0.bias" % i], 1, p.pad, p.pad_mode)
-            x = F.leaky_relu(torch.matmul(self.pool_w[i], x), 0.2)
+            pre = torch.matmul(self.pool_w[i], x)
+            x = F.leaky_relu(pre, 0.2)
+            if branch is not None:
+                amb = pre.detach().abs() < band
+                self.n_ambiguous += int(amb.sum())
+                x = torch.where(amb, torch.where(branch[i], pre, 0.2 * pre), x)
         return x
 
-    def root_velocity(self, joint_pos):
+    def min_abs_preactivation(self, joint_pos):
+        """Smallest |LeakyReLU input| over all layers (tests skip draws where it is within fp32 rounding of 0)."""
+        p, P = self.plan, self.params
+        x = joint_pos.float().transpose(1, 2)
+        m = float("inf")
+        with torch.no_grad():
+            for i in range(p.L):
+                x = skel_conv(x, P["enc.layers.%d.0.weight" % i], self.masks["enc.layers.%d.0.mask" % i],
+                              P["enc.layers.%d.0.bias" % i], 1, p.pad, p.pad_mode)
+                x = torch.matmul(self.pool_w[i], x)
+                m = min(m, float(x.abs().min()))
+                x = F.leaky_relu(x, 0.2)
+        return m
+
+    def root_velocity(self, joint_pos, branch=None):
         """:220-235 — (B,T,72) normalised joint positions -> (B,T,3) normalised root velocity."""
         p = self.plan
         b, T, _ = joint_pos.shape
-        latent = self.encode(joint_pos.float().transpose(1, 2))
+        latent = self.encode(joint_pos.float().transpose(1, 2), branch)
         k = latent.shape[1] // p.d_model
         feat = latent.reshape(b, k, p.d_model, T).transpose(2, 3).transpose(1, 2).reshape(b, T, -1)
         return F.linear(feat, self.params["fc_mapping.weight"], self.params["fc_mapping.bias"])
@@ -582,12 +607,12 @@ class OracleTrajectory:
             out.append(pose[t] + acc[:, None, :])
         return torch.stack(out, dim=0)
 
-    def train_forward(self, data, backward=True):
+    def train_forward(self, data, backward=True, branch=None):
         """:196-265.  data = the 7-tuple of the loader; uses rot_pos [2], joint_pos [3], root_v [6]."""
         hp = self.hp
         rot_pos, joint_pos, root_v = data[2].float(), data[3].float(), data[6].float()
         b, T, _ = joint_pos.shape
-        out_v = self.root_velocity(joint_pos)
+        out_v = self.root_velocity(joint_pos, branch)
         l_v = ((out_v - root_v) ** 2).mean()
         if hp["use_accumulation_root_v"]:
             pose = rot_pos.reshape(b, T, 24, 3).transpose(0, 1)

@@ -48,6 +48,34 @@ def test_engine_plans_on_cpu(tag):
         tr.model(O.synthetic_batch(2, cfg["train_seq_len"]), cfg, 0)
 
 
+@pytest.mark.parametrize("tag", ["len128", "len40"])
+def test_traj_engine_plans_on_cpu(tag):
+    from hm_vae_amd.trainer_motion_vae import Trainer
+    from hm_vae_amd.traj_engine import TrajEngine
+    from hm_vae_amd import _lib
+    from helpers import load_traj_cfg
+    meta = json.load(open(os.path.join(GOLDEN, "traj_meta.json")))[tag]
+    cfg = load_traj_cfg(meta["T"])
+    tr = Trainer(cfg)
+    assert list(tr.model.state_dict().keys()) == meta["state_dict_keys"]
+    assert [n for n, p in tr.model.named_parameters() if p.requires_grad] == meta["trainable_order"]
+    assert [n for n, p in tr.model.named_parameters()] == meta["all_param_order"]
+    eng = TrajEngine(cfg, dict(tr.model.named_parameters()), [1.0, 1.0, 1.0], "cpu")
+    plan = O.TrajPlan(cfg)
+    p = eng.p
+    assert p.neigh == plan.neigh and p.pooling == plan.pooling and p.edge_num == plan.edge_num
+    assert p.enc_cin == plan.enc_cin and p.enc_cout == plan.enc_cout and p.fc_in == plan.fc_in == 336
+    order, offs, n1, n2 = eng.grad_layout()
+    assert order == meta["trainable_order"] and n1 == n2 == eng.flat_grad.numel()
+    # mask-effective forward MACs per sequence = sum over layers of nnz(mask[:, :, 0]) * K * T, + the 336x3 head per frame
+    macs = sum(int(m[:, :, 0].sum()) * plan.K * plan.T for m in O.traj_masks(plan).values()) + 3 * 336 * plan.T
+    assert eng.flops_per_seq == 2 * macs
+    with pytest.raises(_lib.HmvaeError):
+        eng.workspace(4)
+    with pytest.raises(_lib.HmvaeError):
+        tr.model(O.synthetic_traj_batch(2, meta["T"]), cfg, 0)
+
+
 def test_c_abi_exports_match_header():
     """Every function declared in include/hmvae.h is exported by the built library and bound in _lib."""
     import re

@@ -251,10 +251,17 @@ def traj_golden(B, T, seed):
              model.fc_mapping.register_forward_hook(lambda m, i, o: caps.__setitem__("root_v_out", o))]
     for li, layer in enumerate(model.enc.layers):
         hooks.append(layer.register_forward_hook(lambda m, i, o, li=li: caps.__setitem__("act%d" % li, o)))
+        hooks.append(layer[1].register_forward_hook(lambda m, i, o, li=li: caps.__setitem__("pre%d" % li, o)))
     tr.gen_opt.zero_grad()
     ret = model(data, cfg, 0)
     for h in hooks:
         h.remove()
+    # LeakyReLU is discontinuous in its gradient at 0: a pre-activation within fp32 rounding of 0 makes the backward
+    # pass depend on summation order.  Such a draw cannot pin anything; the caller moves on to the next seed.
+    margin = min(float(caps["pre%d" % li].abs().min()) for li in range(cfg["num_layers"]))
+    if margin < 2e-5:
+        return None, margin
+    store["min_abs_preact"] = np.float64(margin)
     store["ret"] = np.array([float(x) for x in ret], dtype=np.float64)
     store["root_v_out"] = caps["root_v_out"].detach().numpy()
     for li in range(cfg["num_layers"]):
@@ -306,7 +313,13 @@ def main():
         vae_fixtures()
     tmetas = {}
     for tag, B, T, seed in (("len128", 2, 128, 31), ("len40", 3, 40, 41)):
-        store, meta = traj_golden(B, T, seed)
+        store = None
+        while store is None:
+            store, meta = traj_golden(B, T, seed)
+            if store is None:
+                print("traj %s: seed %d has a LeakyReLU input at %.2e, trying the next seed" % (tag, seed, meta))
+                seed += 1
+        meta["seed"] = seed
         np.savez_compressed(os.path.join(OUT, "traj_%s.npz" % tag), **store)
         tmetas[tag] = meta
     json.dump(tmetas, open(os.path.join(OUT, "traj_meta.json"), "w"), indent=1)
