@@ -118,6 +118,62 @@ def test_two_rank_gradient_bucket_allreduce(tmp_path, phase2):
     assert worst < 2e-5, worst
 
 
+def _traj_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from oracle import hmvae_oracle as O
+    from hm_vae_amd import ddp
+    from hm_vae_amd.traj_engine import TrajEngine
+    from hm_vae_amd.trainer_motion_vae import Trainer
+    from helpers import load_traj_cfg, load_traj_golden
+    ddp.init_from_env(backend="gloo")
+    T, B = 40, 4
+    cfg = load_traj_cfg(T)
+    plan = O.TrajPlan(cfg)
+    seeded = O.traj_name_seeded_params(plan)
+    g, _ = load_traj_golden("len40")
+    torch.manual_seed(100 + rank)
+    tr = Trainer(cfg)
+    params = [p for p in tr.model.parameters() if p.requires_grad]
+    ddp.broadcast_parameters(params)
+    chk = torch.stack([p.detach().double().sum() for p in params])
+    gathered = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(gathered, chk)
+    assert all(torch.equal(x, gathered[0]) for x in gathered)
+    full = O.synthetic_traj_batch(B, T, seed=7)
+    shard = ddp.shard_batch(full, rank, world)
+    orc = O.OracleTrajectory(cfg, seeded, g["mean_root"], g["std_root"])
+    orc.train_forward(shard)
+    eng = TrajEngine(cfg, dict(tr.model.named_parameters()), g["std_root"], "cpu")
+    eng.assign_grads()
+    for name, p in orc.trainable():
+        eng.params[name].grad.copy_(p.grad)
+    nfl = eng.active_grad_floats()
+    assert nfl == eng.flat_grad.numel()
+    ddp.all_reduce_mean_(eng.flat_grad[:nfl])
+    if rank == 0:
+        ref = O.OracleTrajectory(cfg, seeded, g["mean_root"], g["std_root"])
+        ref.train_forward(full)
+        worst = 0.0
+        for name, p in ref.trainable():
+            a = eng.params[name].grad.numpy().astype(np.float64)
+            b = p.grad.numpy().astype(np.float64)
+            worst = max(worst, float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)))
+        with open(os.path.join(out_dir, "result_traj.txt"), "w") as f:
+            f.write("%.3e" % worst)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_trajectory_bucket_allreduce(tmp_path):
+    """TrajectoryModel: both losses are batch means, so the mean of the two half-batch gradients is the full-batch one."""
+    port = _free_port()
+    mp.spawn(_traj_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    worst = float(open(os.path.join(str(tmp_path), "result_traj.txt")).read())
+    assert worst < 5e-5, worst
+
+
 def test_single_process_helpers_are_noops():
     from hm_vae_amd import ddp
     assert not ddp.is_distributed() and ddp.rank() == 0 and ddp.world_size() == 1

@@ -226,3 +226,30 @@ def test_traj_checkpoint_roundtrip(dev, tmp_path):
     assert rel_err(np.array(r2), np.array(r_next)) < 1e-6
     sd = torch.load(str(tmp_path / "gen_00000001.pt"), map_location="cpu", weights_only=True)["state_dict"]
     assert list(sd.keys()) == meta["state_dict_keys"]
+
+
+def test_traj_train_cli_runs(dev, tmp_path):
+    """train_motion_vae.py with the trajectory config: three iterations on synthetic batches (FK positions standardised
+    like MotionSeqData does), nine losses printed in the reference's order."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "train_motion_vae.py"), "--config",
+           os.path.join(root, "configs", "trajectory_model.yaml"), "--output_path", str(tmp_path), "--batch_size", "4",
+           "--max_iter", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Training: Total loss" in r.stdout and "Finish Training" in r.stdout
+
+
+def test_traj_synthetic_loader_positions(dev):
+    from hm_vae_amd.utils_motion_vae import SyntheticMotionLoader, load_mean_std
+    from helpers import offsets
+    ld = SyntheticMotionLoader(3, 16, dev, 2, 5, with_positions=True)
+    tup = next(iter(ld))
+    R = tup[1].reshape(48, 24, 3, 3).cpu()
+    pos = O.fk_positions(R, O.SMPL24_PARENTS, torch.from_numpy(offsets()))
+    assert rel_err(tup[2].cpu().numpy().reshape(48, 24, 3), pos.numpy()) < TOL
+    mean, std = load_mean_std()
+    assert rel_err(tup[3].cpu().numpy().reshape(48, 72), (pos.reshape(48, 72).numpy() - mean[360:432]) / std[360:432]) < TOL
