@@ -13,6 +13,7 @@
 //   p_j = p_par + G_par·off_j,  G_j = G_par·R_j
 //   H_j = sum_{c child of j} ( H_c·R_c^T + S_c ⊗ off_c ),   dR_j = dR_j(direct) + G_par^T·H_j
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 #include "hmvae.h"
 
@@ -353,11 +354,24 @@ __device__ __forceinline__ void fk_chain_role(int role, IO& io) {
 constexpr int FK_FRAMES = 32;
 template <int N>   // floats per frame, a multiple of 4; LDS rows are N + 1 apart
 __device__ __forceinline__ void fk_stream_in(const float* __restrict__ src, float* lds, int nf) {
-    for (int i = threadIdx.x; i < nf * (N / 4); i += 256) {
-        const int f = i / (N / 4), q = i - f * (N / 4);
-        const float4 v = *(const float4*)(src + (size_t)f * N + 4 * q);
-        float* l = lds + f * (N + 1) + 4 * q;
-        l[0] = v.x; l[1] = v.y; l[2] = v.z; l[3] = v.w;
+    // every 16-byte load of the tile is issued before the first LDS write: a rolled loop keeps ONE load per thread in
+    // flight (load, wait, 4 ds_writes, repeat), i.e. 4 KB per workgroup against the ~50 KB per CU the HBM latency needs
+    constexpr int IT = (FK_FRAMES * (N / 4) + 255) / 256;
+    float4 v[IT];
+    const int tot = nf * (N / 4);
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int i = threadIdx.x + k * 256;
+        if (i < tot) v[k] = *(const float4*)(src + 4 * (size_t)i);
+    }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int i = threadIdx.x + k * 256;
+        if (i < tot) {
+            const int f = i / (N / 4), q = i - f * (N / 4);
+            float* l = lds + f * (N + 1) + 4 * q;
+            l[0] = v[k].x; l[1] = v[k].y; l[2] = v[k].z; l[3] = v[k].w;
+        }
     }
 }
 template <int N>
@@ -369,41 +383,59 @@ __device__ __forceinline__ void fk_stream_out(const float* lds, float* __restric
     }
 }
 
-template <int RD>
+// PF: per-frame offsets (off_stride = 72) instead of one shared set.  Either way the offsets are staged in LDS with the
+// tile: read from global inside the chain they cost five dependent L2 round trips per workgroup.
+template <int RD, bool PF>
 __global__ __launch_bounds__(256) void fk_fwd_aos_kernel(const float* __restrict__ rot, const float* __restrict__ offs,
-                                                         long long off_stride, long long n, float* __restrict__ R_out,
+                                                         long long n, float* __restrict__ R_out,
                                                          float* __restrict__ P_out) {
     constexpr int LR = NJ * 9 + 1, LP = NJ * 3 + 1, L6 = NJ * 6 + 1;
     __shared__ float sR[FK_FRAMES * LR];
     __shared__ float sP[FK_FRAMES * LP];
-    __shared__ float s6[RD == 6 ? FK_FRAMES * L6 : 1];
+    __shared__ float sO[PF ? FK_FRAMES * LP : NJ * 3];
     const long long f0 = (long long)blockIdx.x * FK_FRAMES;
     const int nf = n - f0 < FK_FRAMES ? (int)(n - f0) : FK_FRAMES;
+    float o_sh = 0.f;                   // issued with the tile's loads, parked in LDS after them
+    if constexpr (!PF) {
+        if (threadIdx.x < NJ * 3) o_sh = offs[threadIdx.x];
+    }
     if constexpr (RD == 9) {
         fk_stream_in<NJ * 9>(rot + f0 * (NJ * 9), sR, nf);
     } else {
+        // the 6D image lives in the front of sR's space (32 x 145 of its 32 x 217 floats): every thread pulls its three
+        // inputs into registers, one barrier, then the lifted matrices overwrite the image.  A separate 18 KB buffer
+        // would leave two instead of four workgroups per CU.
+        float* s6 = sR;
         fk_stream_in<NJ * 6>(rot + f0 * (NJ * 6), s6, nf);
         __syncthreads();
         const int f = threadIdx.x & (FK_FRAMES - 1);
+        constexpr int LIFTS = NJ * FK_FRAMES / 256;
+        float in[LIFTS][6];
+#pragma unroll
+        for (int i = 0; i < LIFTS; ++i) {
+            const int j = (threadIdx.x / FK_FRAMES) + i * (256 / FK_FRAMES);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) in[i][k] = s6[f * L6 + j * 6 + k];
+        }
+        __syncthreads();
         if (f < nf) {
 #pragma unroll
-            for (int i = 0; i < NJ * FK_FRAMES / 256; ++i) {
+            for (int i = 0; i < LIFTS; ++i) {
                 const int j = (threadIdx.x / FK_FRAMES) + i * (256 / FK_FRAMES);
-                float in[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) in[k] = s6[f * L6 + j * 6 + k];
                 M3 Rm;
-                lift6d(in, Rm);
+                lift6d(in[i], Rm);
 #pragma unroll
                 for (int k = 0; k < 9; ++k) sR[f * LR + j * 9 + k] = Rm.a[k];
             }
         }
     }
+    if constexpr (PF) fk_stream_in<NJ * 3>(offs + f0 * (NJ * 3), sO, nf);
+    else if (threadIdx.x < NJ * 3) sO[threadIdx.x] = o_sh;
     __syncthreads();
     {
         const int lane = threadIdx.x & 63;
         if (lane < nf) {
-            ChainAos io{offs + (f0 + lane) * off_stride, sR + lane * LR, sP + lane * LP};
+            ChainAos io{PF ? sO + lane * LP : sO, sR + lane * LR, sP + lane * LP};
             fk_chain_role(threadIdx.x >> 6, io);
         }
     }
@@ -484,12 +516,17 @@ extern "C" int hmvae_fk_fwd(const float* rot, int32_t rot_dim, const float* offs
     if (!is_smpl24(parents_host, n_joints)) return HMVAE_ERR_UNSUPPORTED;
     dim3 grid((unsigned)((n_frames + FK_FRAMES - 1) / FK_FRAMES)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (rot_dim == 6)
-        hipLaunchKernelGGL(fk_fwd_aos_kernel<6>, grid, block, 0, s, rot, offsets, (long long)offset_stride,
-                           (long long)n_frames, R_out, pos_out);
-    else
-        hipLaunchKernelGGL(fk_fwd_aos_kernel<9>, grid, block, 0, s, rot, offsets, (long long)offset_stride,
-                           (long long)n_frames, R_out, pos_out);
+    const bool pf = offset_stride != 0;
+#define FK_FWD_LAUNCH(RD_, PF_) \
+    hipLaunchKernelGGL((fk_fwd_aos_kernel<RD_, PF_>), grid, block, 0, s, rot, offsets, (long long)n_frames, R_out, pos_out)
+    if (rot_dim == 6) {
+        if (pf) FK_FWD_LAUNCH(6, true);
+        else FK_FWD_LAUNCH(6, false);
+    } else {
+        if (pf) FK_FWD_LAUNCH(9, true);
+        else FK_FWD_LAUNCH(9, false);
+    }
+#undef FK_FWD_LAUNCH
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }
 
@@ -750,44 +787,57 @@ struct ChainLds {                        // phase B policy: rotations come from 
 };
 
 constexpr int TF_FRAMES = 32;
-constexpr int TF_GROUPS = 4;             // groups of 32 frames a workgroup walks; the next group's inputs are in flight
-                                         // (registers) while the current group's outputs stream out
+// TF_GROUPS: time steps (groups of 32 frames) a workgroup walks
+// C6: also write the frame-major copy of the 6D input the decode API returns (576 B/frame more to store and 18 KB more
+// LDS: two instead of four workgroups per CU); callers that only want R / positions pass c6 = NULL.
+template <bool C6, int TF_GROUPS>
 __global__ __launch_bounds__(256) void decode_tail_fwd_kernel(const float* __restrict__ dec, const float* __restrict__ offs,
                                                               int T, int B, int bp, float* __restrict__ c6,
                                                               float* __restrict__ R, float* __restrict__ P) {
     constexpr int L6 = NJ * 6 + 1, LR = NJ * 9 + 1, LP = NJ * 3 + 1;
     constexpr int LIFTS = NJ * TF_FRAMES / 256;      // lifts per thread
-    __shared__ float s6[TF_FRAMES * L6];
+    __shared__ float s6[C6 ? TF_FRAMES * L6 : 1];
     __shared__ float sR[TF_FRAMES * LR];
     __shared__ float sP[TF_FRAMES * LP];
-    const int t = blockIdx.y;
+    __shared__ float sO[NJ * 3];                     // offsets: LDS broadcast reads inside the chain, no global round trips
     const size_t rs = (size_t)T * bp;
     const int f = threadIdx.x & (TF_FRAMES - 1);
     const int j0 = threadIdx.x / TF_FRAMES;
-    float in[LIFTS][6];
-    auto load_inputs = [&](int b0) {                 // coalesced 128-byte row pieces; b0 + f < bp always (bp % 64 == 0)
-        const float* x = dec + (size_t)t * bp + b0 + f;
+    // A workgroup owns 32 sequences (b0..b0+31) and TF_GROUPS consecutive time steps.  ALL its inputs are requested up
+    // front: with one group per workgroup in flight a CU holds 4 x 18 KB of loads half of the time, about half of what
+    // the HBM latency needs (bandwidth x latency = ~55 KB per CU); the registers hold the later groups while the first
+    // one is lifted, chained and streamed out.
+    float in[TF_GROUPS][LIFTS][6];
+    const int b0 = blockIdx.x * TF_FRAMES;
+    const int nf = B - b0 < TF_FRAMES ? B - b0 : TF_FRAMES;          // frames of a group
+    const int t0 = blockIdx.y * TF_GROUPS;
 #pragma unroll
-        for (int i = 0; i < LIFTS; ++i) {
-            const int j = j0 + i * (256 / TF_FRAMES);
+    for (int g = 0; g < TF_GROUPS; ++g) {
+        if (t0 + g < T) {                            // coalesced 128-byte row pieces; b0 + f < bp always (bp % 64 == 0)
+            const float* x = dec + (size_t)(t0 + g) * bp + b0 + f;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) in[i][k] = x[(size_t)(j * 6 + k) * rs];
+            for (int i = 0; i < LIFTS; ++i) {
+                const int j = j0 + i * (256 / TF_FRAMES);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) in[g][i][k] = x[(size_t)(j * 6 + k) * rs];
+            }
         }
-    };
-    const int g0 = blockIdx.x * TF_GROUPS;
-    if (g0 * TF_FRAMES < B) load_inputs(g0 * TF_FRAMES);
-    for (int g = g0; g < g0 + TF_GROUPS; ++g) {
-        const int b0 = g * TF_FRAMES;
-        if (b0 >= B) break;
-        const int nf = B - b0 < TF_FRAMES ? B - b0 : TF_FRAMES;      // frames of this group
-        // A: lifts (from the registers loaded one group ahead)
+    }
+    if (threadIdx.x < NJ * 3) sO[threadIdx.x] = offs[threadIdx.x];
+#pragma unroll
+    for (int g = 0; g < TF_GROUPS; ++g) {
+        const int t = t0 + g;
+        if (t >= T) break;
+        // A: lifts
 #pragma unroll
         for (int i = 0; i < LIFTS; ++i) {
             const int j = j0 + i * (256 / TF_FRAMES);
+            if constexpr (C6) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) s6[f * L6 + j * 6 + k] = in[i][k];
+                for (int k = 0; k < 6; ++k) s6[f * L6 + j * 6 + k] = in[g][i][k];
+            }
             M3 Rm;
-            lift6d(in[i], Rm);
+            lift6d(in[g][i], Rm);
 #pragma unroll
             for (int k = 0; k < 9; ++k) sR[f * LR + j * 9 + k] = Rm.a[k];
         }
@@ -796,25 +846,39 @@ __global__ __launch_bounds__(256) void decode_tail_fwd_kernel(const float* __res
         {
             const int lane = threadIdx.x & 63;
             if (lane < nf) {
-                ChainLds io{offs, sR + lane * LR, sP + lane * LP};
+                ChainLds io{sO, sR + lane * LR, sP + lane * LP};
                 fk_chain_role(threadIdx.x >> 6, io);
             }
         }
         __syncthreads();
-        if ((g + 1) < g0 + TF_GROUPS && (g + 1) * TF_FRAMES < B) load_inputs((g + 1) * TF_FRAMES);
         // C: out[(b0 + f) * T + t][0..n): n floats per frame, consecutive threads -> consecutive 16-byte pieces
         auto stream_out = [&](auto n_c, const float* lds, float* out) {
             constexpr int n = decltype(n_c)::value;        // compile-time: the division below is a multiply
             // 16-byte stores (a quarter of the store instructions; the four LDS reads per lane are 4-way bank conflicted,
-            // which is cheaper than the extra global stores: 165 vs 182 us at 262 144 frames)
-            for (int i = threadIdx.x; i < nf * (n / 4); i += 256) {
-                const int fr = i / (n / 4), q = i - fr * (n / 4);
-                const float* l = lds + fr * (n + 1) + 4 * q;
-                const float4 v = {l[0], l[1], l[2], l[3]};
-                *(float4*)(out + ((size_t)(b0 + fr) * T + t) * n + 4 * q) = v;
+            // which is cheaper than the extra global stores: 165 vs 182 us at 262 144 frames).  Unrolled: all LDS reads of
+            // a thread are issued before its first store instead of one read-wait-store round per iteration.
+            constexpr int IT = (TF_FRAMES * (n / 4) + 255) / 256;
+            float4 v[IT];
+            const int tot = nf * (n / 4);
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int i = threadIdx.x + k * 256;
+                if (i < tot) {
+                    const int fr = i / (n / 4), q = i - fr * (n / 4);
+                    const float* l = lds + fr * (n + 1) + 4 * q;
+                    v[k] = float4{l[0], l[1], l[2], l[3]};
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int i = threadIdx.x + k * 256;
+                if (i < tot) {
+                    const int fr = i / (n / 4), q = i - fr * (n / 4);
+                    *(float4*)(out + ((size_t)(b0 + fr) * T + t) * n + 4 * q) = v[k];
+                }
             }
         };
-        stream_out(std::integral_constant<int, NJ * 6>{}, s6, c6);
+        if constexpr (C6) stream_out(std::integral_constant<int, NJ * 6>{}, s6, c6);
         stream_out(std::integral_constant<int, NJ * 9>{}, sR, R);
         stream_out(std::integral_constant<int, NJ * 3>{}, sP, P);
         __syncthreads();                                   // the image is rewritten by the next group
@@ -838,9 +902,31 @@ extern "C" int hmvae_decode_tail_loss(const float* dec_out, const float* gt6d, c
 
 extern "C" int hmvae_decode_tail_fwd(const float* dec_out, const float* offsets, int32_t T, int32_t B, int32_t bp,
                                      float* c6, float* R, float* pos, hmvae_stream_t stream) {
-    if (!dec_out || !offsets || !c6 || !R || !pos) return HMVAE_ERR_ARG;
+    if (!dec_out || !offsets || !R || !pos) return HMVAE_ERR_ARG;
     if (T <= 0 || T > 65535 || B <= 0 || bp < B || (bp & 63)) return HMVAE_ERR_ARG;
-    dim3 grid((B + TF_FRAMES * TF_GROUPS - 1) / (TF_FRAMES * TF_GROUPS), T), block(256);
-    hipLaunchKernelGGL(decode_tail_fwd_kernel, grid, block, 0, (hipStream_t)stream, dec_out, offsets, T, B, bp, c6, R, pos);
+    static int groups = 0;
+    if (!groups) {
+        const char* e = getenv("HMVAE_TF_GROUPS");
+        groups = e ? atoi(e) : 1;        // measured at 262 144 frames: 104 / 107 / 113 / 123 us for 1 / 2 / 4 / 8
+        if (groups != 1 && groups != 2 && groups != 4) groups = 1;
+    }
+    dim3 block(256);
+#define TF_LAUNCH(C6_, G_)                                                                                             \
+    hipLaunchKernelGGL((decode_tail_fwd_kernel<C6_, G_>), dim3((B + TF_FRAMES - 1) / TF_FRAMES, (T + G_ - 1) / G_), block, \
+                       0, (hipStream_t)stream, dec_out, offsets, T, B, bp, c6, R, pos)
+#define TF_PICK(C6_)                              \
+    switch (groups) {                             \
+        case 1: TF_LAUNCH(C6_, 1); break;         \
+        case 2: TF_LAUNCH(C6_, 2); break;         \
+        case 4: TF_LAUNCH(C6_, 4); break;         \
+        default: TF_LAUNCH(C6_, 1); break;        \
+    }
+    if (c6) {
+        TF_PICK(true)
+    } else {
+        TF_PICK(false)
+    }
+#undef TF_PICK
+#undef TF_LAUNCH
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }

@@ -638,8 +638,9 @@ class VaeEngine(_StepBase):
         ops.aos_to_soa(z0.contiguous(), w["Z0"], B, 1, z0.shape[1] * z0.shape[2], bp)
         ops.aos_to_soa(z_deep.contiguous(), w["Z%d" % (L - 1)], B, 1, z_deep.shape[1] * z_deep.shape[2], bp)
 
-    def decode(self, z0, z_deep, repack=True):
-        """_decode (seq_two_hier_sa_vae.py:436-474): returns AoS (c6 (B,T,24,6), R (B,T,24,3,3), pos (B,T,24,3))."""
+    def decode(self, z0, z_deep, repack=True, need_c6=True):
+        """_decode (seq_two_hier_sa_vae.py:436-474): returns AoS (c6 (B,T,24,6), R (B,T,24,3,3), pos (B,T,24,3)).
+        need_c6=False skips the frame-major copy of the 6D decoder output (c6 is None): test()/gen_seq only use pos."""
         B = z0.shape[0]
         w = self.workspace(B)
         if repack:
@@ -647,7 +648,7 @@ class VaeEngine(_StepBase):
         self.load_latents(w, z0, z_deep)
         self.decode_feats(w)
         T = self.p.T
-        c6 = torch.empty(B, T, 24, 6, device=self.device)
+        c6 = torch.empty(B, T, 24, 6, device=self.device) if need_c6 else None
         R = torch.empty(B, T, 24, 3, 3, device=self.device)
         pos = torch.empty(B, T, 24, 3, device=self.device)
         ops.decode_tail_fwd(w["D%d" % (self.p.L - 1)], self.offsets, T, B, w["bp"], c6, R, pos)

@@ -203,12 +203,13 @@ class TwoHierSAVAEModel(nn.Module):
         assert pred.size() == gt.size()
         return ((pred - gt) ** 2).mean()
 
-    def _decode(self, z_list, adjust_root_rot_flag=False, relative_root_rot=None):
-        """z_list: per-level latents (shallow..deep).  Returns the reference 7-tuple (last four are None)."""
+    def _decode(self, z_list, adjust_root_rot_flag=False, relative_root_rot=None, need_c6=True):
+        """z_list: per-level latents (shallow..deep).  Returns the reference 7-tuple (last four are None).
+        need_c6=False (not in the reference): the first element is None and the kernel skips writing it."""
         eng = self.engine()
         z0, zd = self._dev(z_list[0]), self._dev(z_list[-1])
         with torch.no_grad():
-            c6, R, pos = eng.decode(z0, zd)
+            c6, R, pos = eng.decode(z0, zd, need_c6=need_c6)
             if adjust_root_rot_flag:       # visualisation-only branch of the reference (:457-465)
                 bs, T = R.shape[0], R.shape[1]
                 if relative_root_rot is not None:
@@ -251,11 +252,11 @@ class TwoHierSAVAEModel(nn.Module):
                 mean_z.append(dist[:, :, :d].contiguous())
                 sampled_z.append(torch.randn_like(mean_z[-1]))
             if hp['random_root_rot_flag']:
-                mean_pos = self._decode(mean_z, adjust_root_rot_flag=True, relative_root_rot=rel)[2]
-                samp_pos = self._decode(sampled_z, adjust_root_rot_flag=True)[2]
+                mean_pos = self._decode(mean_z, adjust_root_rot_flag=True, relative_root_rot=rel, need_c6=False)[2]
+                samp_pos = self._decode(sampled_z, adjust_root_rot_flag=True, need_c6=False)[2]
             else:
-                mean_pos = self._decode(mean_z)[2]
-                samp_pos = self._decode(sampled_z)[2]
+                mean_pos = self._decode(mean_z, need_c6=False)[2]
+                samp_pos = self._decode(sampled_z, need_c6=False)[2]
         return gt_seq_res, mean_pos.transpose(0, 1), samp_pos.transpose(0, 1), None
 
     def gen_seq(self, data, hp, iterations):

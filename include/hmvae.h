@@ -341,7 +341,8 @@ int hmvae_decode_tail_loss(const float* dec_out, const float* gt6d, const float*
                            const float* offsets, int32_t T, int32_t B, int32_t bp, float scale_6d, float scale_rot,
                            float scale_pos, float* d_dec_out, float* partial, int32_t* n_blocks_out,
                            hmvae_stream_t stream);
-/* decode tail, inference: SoA decoder output -> AoS cont6d (B,T,24,6), R (B,T,24,3,3), pos (B,T,24,3) */
+/* decode tail, inference: SoA decoder output -> AoS cont6d (B,T,24,6), R (B,T,24,3,3), pos (B,T,24,3).
+ * c6 may be NULL (the frame-major copy of the 6D input is then not written). */
 int hmvae_decode_tail_fwd(const float* dec_out, const float* offsets, int32_t T, int32_t B, int32_t bp, float* c6,
                           float* R, float* pos, hmvae_stream_t stream);
 

@@ -447,6 +447,10 @@ def test_decode_tail_loss_and_fwd(dev, B, T):
     assert rel_err(c6o.cpu().numpy().reshape(B * T, 24, 6), d6.detach().numpy()) < 1e-6
     assert rel_err(Ro.cpu().numpy().reshape(B * T, 24, 3, 3), R.detach().numpy()) < 1e-5
     assert rel_err(Po.cpu().numpy().reshape(B * T, 24, 3), Pp.detach().numpy()) < 1e-5
+    # without the 6D copy (what test()/gen_seq launch): identical R / positions
+    Ro2, Po2 = torch.zeros_like(Ro), torch.zeros_like(Po)
+    ops.decode_tail_fwd(decs, offd, T, B, bp, None, Ro2, Po2)
+    assert torch.equal(Ro2, Ro) and torch.equal(Po2, Po)
 
 
 def test_adam_matches_torch(dev):
