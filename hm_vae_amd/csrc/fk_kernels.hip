@@ -605,7 +605,10 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     return v;
 }
 
-// One workgroup = 64 frames x 4 waves.  A frame's work is split by SUBTREE over the waves (a wave runs one role, so
+// One workgroup = TL_FRAMES frames x 4 waves (lanes >= TL_FRAMES idle).  The kernel is latency-bound -- every joint step
+// waits for its own loads -- so at the 16 384 frames of the training step 32-frame workgroups (two per CU) run the same
+// dependent chain twice as often in parallel as 64-frame ones (one per CU).
+// A frame's work is split by SUBTREE over the waves (a wave runs one role, so
 // there is no divergence and every load/store stays a 256-byte row segment): one thread per frame left 3 of 4 SIMDs
 // without a wave at the 16 384 frames of the training step and ran ~120 us on the critical path.
 //   wave 1: the legs (subtrees of joints 1 and 2, hanging off the root)
@@ -613,20 +616,22 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 //   wave 0: the head (subtree of 12), then -- after one barrier -- the trunk 9 -> 6 -> 3 -> 0 with the limbs' sums
 // Every wave recomputes the trunk's forward chain it needs (<= 4 lifts + 3 products); a limb hands its parent
 // S = sum of dP over the subtree and H = H_c R_c^T + S (x) off_c through LDS (12 floats per frame).
+constexpr int TL_FRAMES = 32;
 __global__ __launch_bounds__(256) void decode_tail_loss_kernel(const float* __restrict__ dec, const float* __restrict__ g6,
                                                                const float* __restrict__ gR, const float* __restrict__ gP,
                                                                const float* __restrict__ offs, int T, int B, int bp,
                                                                float c6, float cR, float cP, float* __restrict__ ddec,
                                                                float* __restrict__ partial) {
-    __shared__ float xch[4][12][64];                  // [limb][S(3) + H(9)][frame]
+    __shared__ float xch[4][12][TL_FRAMES];           // [limb][S(3) + H(9)][frame]
     __shared__ float psum[4][3];
     const int lane = threadIdx.x & 63;
     const int role = threadIdx.x >> 6;                // wave-uniform
-    const int b = blockIdx.x * 64 + lane;
+    const int b = blockIdx.x * TL_FRAMES + (lane & (TL_FRAMES - 1));
     const int t = blockIdx.y;
     const size_t rs = (size_t)T * bp;
     const size_t o = (size_t)t * bp + b;
-    const bool live = b < B;
+    const bool mine = lane < TL_FRAMES;
+    const bool live = mine && b < B;
     TailLoss io{dec + o, g6 + o, gR + o, gP + o, offs, ddec + o, rs, 0.f, 0.f, 0.f, c6, cR, cP};
     auto hand_over = [&](int slot, const V3& S, const M3& H) {
         xch[slot][0][lane] = S.x;
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(256) void decode_tail_loss_kernel(const float* __re
             limb(std::integral_constant<int, 12>{}, G9, P9, S, H);
         }
         hand_over(role, S, H);
-    } else if (b < bp && role == 0) {
+    } else if (mine && b < bp && role == 0) {
         for (int r = 0; r < NJ * 6; ++r) ddec[o + (size_t)r * rs] = 0.f;   // padded batch columns carry zero gradient
     }
     __syncthreads();
@@ -891,10 +896,11 @@ extern "C" int hmvae_decode_tail_loss(const float* dec_out, const float* gt6d, c
                                       const float* offsets, int32_t T, int32_t B, int32_t bp, float scale_6d,
                                       float scale_rot, float scale_pos, float* d_dec_out, float* partial,
                                       int32_t* n_blocks_out, hmvae_stream_t stream) {
-    if (!dec_out || !gt6d || !gtR || !gtP || !offsets || !d_dec_out || !partial) return HMVAE_ERR_ARG;
     if (T <= 0 || T > 65535 || B <= 0 || bp < B || (bp & 63)) return HMVAE_ERR_ARG;
-    dim3 grid(bp / 64, T), block(256);
+    dim3 grid(bp / TL_FRAMES, T), block(256);
     if (n_blocks_out) *n_blocks_out = (int32_t)(grid.x * grid.y);
+    if (!dec_out && !gt6d && !gtR && !gtP && !d_dec_out && !partial) return HMVAE_OK;      // size query
+    if (!dec_out || !gt6d || !gtR || !gtP || !offsets || !d_dec_out || !partial) return HMVAE_ERR_ARG;
     hipLaunchKernelGGL(decode_tail_loss_kernel, grid, block, 0, (hipStream_t)stream, dec_out, gt6d, gtR, gtP, offsets, T, B,
                        bp, 2.f * scale_6d, 2.f * scale_rot, 2.f * scale_pos, d_dec_out, partial);
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;

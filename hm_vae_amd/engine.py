@@ -270,7 +270,7 @@ class VaeEngine(_StepBase):
             else:
                 rows = p.dec_cout[i] * t_conv
             w["D%d" % i], w["dD%d" % i] = buf(rows), buf(rows)
-        w["MSEP"] = torch.zeros((bp // 64) * T0, 3, device=dev)
+        w["MSEP"] = torch.zeros(ops.decode_tail_loss_blocks(T0, B, bp), 3, device=dev)
         w["losses"] = torch.zeros(8, device=dev)
         # one slab per weight tensor: the weight-gradient GEMMs run on side streams and are all reduced together at the
         # end of the backward pass (one launch)

@@ -916,6 +916,13 @@ def fk_bwd(rot, rot_dim, offsets, offset_stride, parents, n_frames, dR, dpos, d_
                "fk_bwd")
 
 
+def decode_tail_loss_blocks(T, B, bp):
+    nb = C.c_int32(0)
+    _lib.check(_lib.load().hmvae_decode_tail_loss(None, None, None, None, None, T, B, bp, 0.0, 0.0, 0.0, None, None,
+                                                  C.byref(nb), None), "decode_tail_loss")
+    return nb.value
+
+
 def decode_tail_loss(dec, g6, gR, gP, offsets, T, B, bp, s6, sR, sP, ddec, partial):
     nb = C.c_int32(0)
     _lib.check(_lib.load().hmvae_decode_tail_loss(_lib.ptr(dec), _lib.ptr(g6), _lib.ptr(gR), _lib.ptr(gP),

@@ -336,7 +336,8 @@ int hmvae_fk_bwd(const float* rot, int32_t rot_dim, const float* offsets, int64_
 
 /* seq_two_hier_sa_vae.py:436-474 (decode tail) fused with the three MSEs of :395-397/:430-434 and their
  * backward: SoA decoder output (144 rows x T) and SoA targets -> per-block loss partials + dL/d(dec_out).
- * scale_* = weight / numel of each MSE.  partial: [n_blocks][3] sums of squared errors (6d, rot, pos). */
+ * scale_* = weight / numel of each MSE.  partial: [n_blocks][3] sums of squared errors (6d, rot, pos); with every
+ * buffer NULL only *n_blocks_out is set (size query). */
 int hmvae_decode_tail_loss(const float* dec_out, const float* gt6d, const float* gtR, const float* gtP,
                            const float* offsets, int32_t T, int32_t B, int32_t bp, float scale_6d, float scale_rot,
                            float scale_pos, float* d_dec_out, float* partial, int32_t* n_blocks_out,

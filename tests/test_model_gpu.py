@@ -222,7 +222,8 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     assert it == 1
     tr2.model.eps_override = golden_eps(g)
     r2 = tr2.gen_update(batch, cfg2, it, False)
-    assert rel_err(np.array(r2), np.array(r_next)) < 1e-6
+    # two trainers, each timing its own kernel variants: equal up to fp32 summation order
+    assert rel_err(np.array(r2), np.array(r_next)) < 5e-6
     sd = torch.load(str(tmp_path / "gen_00000001.pt"), map_location="cpu", weights_only=True)["state_dict"]
     assert list(sd.keys()) == meta["state_dict_keys"]
     opt = torch.load(str(tmp_path / "optimizer.pt"), map_location="cpu", weights_only=True)["gen"]
@@ -265,7 +266,8 @@ def test_graph_replay_split_path_matches_single_graph(dev, monkeypatch):
         outs.append((np.array(losses), params))
     # step 1 is the same arithmetic up to the autotuner's choice of summation order; later steps amplify that noise
     # through training (ill-conditioned Adam updates of ~eps-sized gradients), so they get a looser bound
-    assert rel_err(outs[1][0][0, :5], outs[0][0][0, :5]) < 1e-6
+    # (two engines, each timing its own kernel variants: observed up to 1.3e-6 between fp32 summation orders)
+    assert rel_err(outs[1][0][0, :5], outs[0][0][0, :5]) < 5e-6
     assert rel_err(outs[1][0][:, :5], outs[0][0][:, :5]) < 5e-4
     frac_close = float((np.abs(outs[1][1] - outs[0][1]) < 1e-5).mean())
     assert frac_close > 0.999, frac_close

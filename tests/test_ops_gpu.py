@@ -427,7 +427,7 @@ def test_decode_tail_loss_and_fwd(dev, B, T):
 
     g6s, gRs, gPs = tgt_soa(g6, 144), tgt_soa(gR, 216), tgt_soa(gP, 72)
     dd = torch.full((144 * T, bp), float("nan"), device=dev)
-    part = torch.full(((bp // 64) * T, 3), float("nan"), device=dev)
+    part = torch.full((ops.decode_tail_loss_blocks(T, B, bp), 3), float("nan"), device=dev)
     offd = off.to(dev)
     nb = ops.decode_tail_loss(decs, g6s, gRs, gPs, offd, T, B, bp, w6 / (B * T * 144), wR / (B * T * 216),
                               wP / (B * T * 72), dd, part)

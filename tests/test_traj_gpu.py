@@ -223,7 +223,8 @@ def test_traj_checkpoint_roundtrip(dev, tmp_path):
     it = tr2.resume(str(tmp_path), cfg2, False)
     assert it == 1
     r2 = tr2.gen_update(batch, cfg2, it, False)
-    assert rel_err(np.array(r2), np.array(r_next)) < 1e-6
+    # two trainers, each timing its own kernel variants: equal up to fp32 summation order
+    assert rel_err(np.array(r2), np.array(r_next)) < 5e-6
     sd = torch.load(str(tmp_path / "gen_00000001.pt"), map_location="cpu", weights_only=True)["state_dict"]
     assert list(sd.keys()) == meta["state_dict_keys"]
 
