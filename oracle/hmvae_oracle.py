@@ -644,6 +644,60 @@ def synthetic_traj_batch(b, T, seed=0, nj=24):
     return (z144, z216, rot_pos.reshape(b, T, nj * 3), joint_pos, z72, z72.clone(), root_v)
 
 
+# --------------------------------------------------------------------------------------
+# data path: MotionSeqData.__getitem__ (utils_motion_vae.py:124-187) — SURVEY.md §8 row f-3
+# --------------------------------------------------------------------------------------
+FPS_STRIDES = (1, 2, 3, 4, 5, 6, 8, 10, 12)            # utils_motion_vae.py:71
+
+
+def rand_rotation_from_uniforms(randnums, deflection=1.0):
+    """utils_motion_vae.py:16-57 (Graphics Gems III rand_rotation): three uniforms in [0,1] -> 3x3 matrix (float64)."""
+    theta, phi, z = (float(v) for v in randnums)
+    theta = theta * 2.0 * deflection * np.pi
+    phi = phi * 2.0 * np.pi
+    z = z * 2.0 * deflection
+    r = np.sqrt(z)
+    V = (np.sin(phi) * r, np.cos(phi) * r, np.sqrt(2.0 - z))
+    st, ct = np.sin(theta), np.cos(theta)
+    Rz = np.array(((ct, st, 0), (-st, ct, 0), (0, 0, 1)))
+    return (np.outer(V, V) - np.eye(3)).dot(Rz)
+
+
+def motion_item(seq, mean_std, T, crop_start, stride=1, root_rot=None):
+    """One training clip as MotionSeqData.__getitem__ builds it, with the random choices made explicit.
+
+    seq: (T_all, 579) array as stored on disk; mean_std: (2, 579) with zero std already replaced by 1 (:100-101);
+    stride: the frame stride picked by change_fps (:66-83; 1 = no fps augmentation); crop_start: `random_t_idx` (:137),
+    an index into the strided sequence; root_rot: the 3x3 matrix of rand_rotation_matrix() when random_root_rot_flag.
+    Returns the 7-tuple of (T, n) float32 arrays (:187).
+    """
+    ori = np.asarray(seq)[0::stride, :]
+    assert ori.shape[0] >= T and 0 <= crop_start <= ori.shape[0] - T
+    std = (ori - mean_std[0][None, :]) / mean_std[1][None, :]                 # :142, float64 arithmetic
+    raw = torch.from_numpy(np.ascontiguousarray(ori[crop_start:crop_start + T, :])).float()
+    nrm = torch.from_numpy(np.ascontiguousarray(std[crop_start:crop_start + T, :])).float()
+    r6 = raw[:, 0:144]
+    rmat = raw[:, 144:360].clone()
+    rot_pos = raw[:, 360:432]
+    joint_pos, lin_v, ang_v, root_v = nrm[:, 360:432], nrm[:, 432:504], nrm[:, 504:576], nrm[:, 576:579]
+    if root_rot is not None:                                                  # :161-185
+        M = torch.from_numpy(np.asarray(root_rot)).float()[None].repeat(T, 1, 1)
+        root = rmat[:, :9].reshape(-1, 3, 3)
+        aug_v = torch.matmul(M, raw[:, 576:579][:, :, None]).squeeze(-1)
+        root_v = ((aug_v.double() - torch.from_numpy(mean_std[0][None, 576:579])) /
+                  torch.from_numpy(mean_std[1][None, 576:579])).float()
+        rmat[:, :9] = torch.matmul(M, root).reshape(-1, 9)
+        Rm = rmat.reshape(-1, 24, 3, 3)
+        r6 = torch.stack((Rm[:, :, :, 0], Rm[:, :, :, 1]), dim=-2).reshape(T, 144)
+    return tuple(np.ascontiguousarray(t.numpy()) for t in (r6, rmat, rot_pos, joint_pos, lin_v, ang_v, root_v))
+
+
+def synthetic_motion_files(seed=77, lengths=(30, 47, 200, 12)):
+    """Synthetic on-disk sequences (T_i x 579 float32) for the data-path fixtures; regenerated from the seed on both sides."""
+    rng = np.random.default_rng(seed)
+    return [rng.standard_normal((n, 579)).astype(np.float32) for n in lengths]
+
+
 def make_adam(oracle, hp):
     """trainer_motion_vae.py:29-33 — Adam over requires_grad params + StepLR."""
     opt = torch.optim.Adam([t for _, t in oracle.trainable()], lr=hp["lr"], weight_decay=hp["weight_decay"])

@@ -305,12 +305,89 @@ def vae_fixtures():
     json.dump(metas, open(os.path.join(OUT, "model_meta.json"), "w"), indent=1)
 
 
+def loader_golden():
+    """MotionSeqData.__getitem__ (utils_motion_vae.py:124-187) on synthetic T x 579 files, every random choice logged."""
+    import random
+    import tempfile
+    import utils_motion_vae as RU
+    seqs = O.synthetic_motion_files()
+    tmp = tempfile.mkdtemp()
+    ids = {}
+    for i, a in enumerate(seqs):
+        np.save(os.path.join(tmp, "s%d.npy" % i), a)
+        ids[str(i)] = "s%d.npy" % i
+    jf = os.path.join(tmp, "ids.json")
+    json.dump(ids, open(jf, "w"))
+    ms_path = os.path.join(H.REF_ROOT, "utils/data/for_all_data_motion_model/all_amass_data_mean_std.npy")
+    log = []
+    orig_sample, orig_uniform = random.sample, np.random.uniform
+
+    def sample(pop, k):
+        r = orig_sample(pop, k)
+        log.append(("s", int(r[0])))
+        return r
+
+    def uniform(*a, **k):
+        r = orig_uniform(*a, **k)
+        log.append(("u", [float(v) for v in np.asarray(r).reshape(-1)]))
+        return r
+
+    store, meta = {}, []
+    random.seed(5)
+    np.random.seed(6)
+    random.sample, np.random.uniform = sample, uniform
+    try:
+        ci = 0
+        for T, fps, rot in ((16, False, False), (16, True, False), (16, False, True), (8, True, True)):
+            ds = RU.MotionSeqData(tmp, jf, ms_path, {"train_seq_len": T}, fps_aug_flag=fps, random_root_rot_flag=rot)
+            for idx in range(len(seqs)):
+                del log[:]
+                out = ds[idx]
+                # replay the log with the control flow of __getitem__ / change_fps to name the choices
+                pos, cur = 0, idx
+                while True:
+                    n, stride = seqs[cur].shape[0], 1
+                    if fps:
+                        for _ in range(10):
+                            f = log[pos][1]
+                            pos += 1
+                            if len(range(0, n, f)) >= T:
+                                stride = f
+                                break
+                    n2 = len(range(0, n, stride))
+                    if T <= n2:
+                        crop = log[pos][1]
+                        pos += 1
+                        break
+                    cur = log[pos][1]
+                    pos += 1
+                rn = None
+                if rot:
+                    rn = log[pos][1]
+                    pos += 1
+                assert pos == len(log), (pos, log)
+                for k, t in enumerate(out):
+                    store["c%d|out%d" % (ci, k)] = np.asarray(t.numpy(), dtype=np.float32)
+                meta.append({"case": ci, "T": T, "fps": fps, "rot": rot, "asked": idx, "seq": cur, "stride": stride,
+                             "crop": crop, "randnums": rn})
+                ci += 1
+    finally:
+        random.sample, np.random.uniform = orig_sample, orig_uniform
+    np.savez_compressed(os.path.join(OUT, "loader.npz"), **store)
+    json.dump(meta, open(os.path.join(OUT, "loader_meta.json"), "w"), indent=1)
+
+
 def main():
     only_traj = "--traj-only" in sys.argv
+    only_loader = "--loader-only" in sys.argv
     H.install()
     os.makedirs(OUT, exist_ok=True)
+    if only_loader:
+        loader_golden()
+        return
     if not only_traj:
         vae_fixtures()
+        loader_golden()
     tmetas = {}
     for tag, B, T, seed in (("len128", 2, 128, 31), ("len40", 3, 40, 41)):
         store = None
