@@ -74,6 +74,11 @@ class RowsumOp(C.Structure):
                 ("n_cols", _i32), ("accumulate", _i32), ("block_start", _i32)]
 
 
+class Clip(C.Structure):
+    """hmvae_clip (include/hmvae.h): one clip of a batch assembled by hmvae_motion_batch."""
+    _fields_ = [("row0", _i64), ("stride", _i32), ("reserved", _i32), ("rot", _f32 * 9), ("pad_", _f32 * 3)]
+
+
 class AdamTensor(C.Structure):
     _fields_ = [("p", _ptr), ("g", _ptr), ("m", _ptr), ("v", _ptr), ("n", _i64)]
 
@@ -114,6 +119,7 @@ _SIGS = {
     "hmvae_vae_loss_finalize": ([_ptr, _i32, _ptr, _i32, _ptr, _i32] + [_f32] * 10 + [_ptr, _ptr], _i32),
     "hmvae_finalize_sums": ([_ptr, _i32, _i32, _i32, _f32, _ptr, _ptr], _i32),
     "hmvae_traj_loss": ([_ptr, _ptr, _ptr, _i32, _i32, _i32, _f32, _f32, _ptr, _ptr, _ptr, _ptr], _i32),
+    "hmvae_motion_batch": ([_ptr, _i64, _ptr, _ptr, _ptr, _i32, _i32, _i32] + [_ptr] * 7 + [_ptr], _i32),
     "hmvae_traj_loss_finalize": ([_ptr, _i32, _f32, _f32, _f32, _ptr, _ptr], _i32),
     "hmvae_adam_step": ([_ptr, _i32, _i64, _ptr, _ptr, _f32, _f32, _f32, _f32, _ptr], _i32),
 }

@@ -577,6 +577,86 @@ extern "C" int hmvae_traj_loss_finalize(const float* partial, int32_t n_blocks, 
     return LAUNCH_OK();
 }
 
+// ---------------- batch assembly from a device-resident dataset (utils_motion_vae.py:124-187) ----------------
+// frames: the packed T_i x 579 sequences, back to back.  One workgroup builds MB_FRAMES consecutive frames of one clip:
+// every source column is read once (coalesced) and lands in the 7 output tensors of the reference's batch tuple.
+//   [0:144) 6D, [144:360) rotation matrices, [360:432) FK positions (raw -> seq_rot_pos, standardised -> seq_joint_pos),
+//   [432:504) / [504:576) velocities (standardised), [576:579) root velocity (standardised)
+// Standardisation is done in float64 and rounded once, like the reference (numpy float64 table, then .float()).
+// rot_flag (random_root_rot_flag, :161-185): root matrix <- M * root, every joint's 6D re-read from the matrices
+// ([col0 | col1]), root velocity <- standardise(M * raw root velocity).
+constexpr int MB_FRAMES = 4;
+constexpr int MB_COLS = 579;
+__global__ __launch_bounds__(256) void motion_batch_kernel(const float* __restrict__ frames, long long n_rows,
+                                                           const hmvae_clip* __restrict__ clips,
+                                                           const double* __restrict__ mean, const double* __restrict__ stdv,
+                                                           int T, int rot_flag, float* __restrict__ r6,
+                                                           float* __restrict__ rmat, float* __restrict__ rot_pos,
+                                                           float* __restrict__ joint_pos, float* __restrict__ lin_v,
+                                                           float* __restrict__ ang_v, float* __restrict__ root_v) {
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * MB_FRAMES;
+    const hmvae_clip cl = clips[b];
+    for (int i = threadIdx.x; i < MB_FRAMES * MB_COLS; i += 256) {
+        const int f = i / MB_COLS, c = i - f * MB_COLS;
+        const int t = t0 + f;
+        if (t >= T) break;
+        long long row = cl.row0 + (long long)t * cl.stride;
+        row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);          // descriptors are validated on the host
+        const float* src = frames + row * MB_COLS;
+        const size_t fo = (size_t)b * T + t;
+        const float x = src[c];
+        if (c < 144) {
+            float v = x;
+            if (rot_flag) {
+                const int j = c / 6, r = c - j * 6, a = r / 3, ii = r - a * 3;   // [col a][row ii] of joint j
+                if (j == 0) v = (cl.rot[ii * 3] * src[144 + a] + cl.rot[ii * 3 + 1] * src[147 + a]) + cl.rot[ii * 3 + 2] * src[150 + a];
+                else v = src[144 + j * 9 + ii * 3 + a];
+            }
+            r6[fo * 144 + c] = v;
+        } else if (c < 360) {
+            const int k = c - 144;
+            float v = x;
+            if (rot_flag && k < 9) {
+                const int ii = k / 3, jj = k - ii * 3;
+                v = (cl.rot[ii * 3] * src[144 + jj] + cl.rot[ii * 3 + 1] * src[147 + jj]) + cl.rot[ii * 3 + 2] * src[150 + jj];
+            }
+            rmat[fo * 216 + k] = v;
+        } else {
+            const float n = (float)(((double)x - mean[c]) / stdv[c]);
+            if (c < 432) {
+                rot_pos[fo * 72 + (c - 360)] = x;
+                joint_pos[fo * 72 + (c - 360)] = n;
+            } else if (c < 504) {
+                lin_v[fo * 72 + (c - 432)] = n;
+            } else if (c < 576) {
+                ang_v[fo * 72 + (c - 504)] = n;
+            } else {
+                const int ii = c - 576;
+                float v = n;
+                if (rot_flag) {
+                    const float av = (cl.rot[ii * 3] * src[576] + cl.rot[ii * 3 + 1] * src[577]) + cl.rot[ii * 3 + 2] * src[578];
+                    v = (float)(((double)av - mean[c]) / stdv[c]);
+                }
+                root_v[fo * 3 + ii] = v;
+            }
+        }
+    }
+}
+
+extern "C" int hmvae_motion_batch(const float* frames, int64_t n_rows, const hmvae_clip* clips_dev, const double* mean,
+                                  const double* stdv, int32_t B, int32_t T, int32_t rot_flag, float* r6, float* rmat,
+                                  float* rot_pos, float* joint_pos, float* lin_v, float* ang_v, float* root_v,
+                                  hmvae_stream_t stream) {
+    if (!frames || !clips_dev || !mean || !stdv || !r6 || !rmat || !rot_pos || !joint_pos || !lin_v || !ang_v || !root_v)
+        return HMVAE_ERR_ARG;
+    if (n_rows <= 0 || B <= 0 || B > 65535 || T <= 0) return HMVAE_ERR_ARG;
+    dim3 grid((unsigned)((T + MB_FRAMES - 1) / MB_FRAMES), (unsigned)B);
+    hipLaunchKernelGGL(motion_batch_kernel, grid, dim3(256), 0, (hipStream_t)stream, frames, (long long)n_rows, clips_dev, mean,
+                       stdv, T, rot_flag, r6, rmat, rot_pos, joint_pos, lin_v, ang_v, root_v);
+    return LAUNCH_OK();
+}
+
 // ---------------- Adam ----------------
 __global__ __launch_bounds__(256) void adam_kernel(const hmvae_adam_tensor* __restrict__ tab,
                                                     const float* __restrict__ lr_dev, const int* __restrict__ step_dev,

@@ -370,6 +370,25 @@ int hmvae_finalize_sums(const float* partial, int32_t n_partial, int32_t stride,
                         hmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Batch assembly from a device-resident dataset — MotionSeqData.__getitem__ (utils_motion_vae.py:124-187) for a whole
+ * batch in one launch.  frames: the `T_i x 579` sequences of the on-disk format (utils/process_all_data_motion.py:155-158)
+ * packed back to back, n_rows in total.  One descriptor per clip, built by the host sampler: first source row, frame
+ * stride (change_fps, :66-83), and the root rotation of rand_rotation_matrix (:16-57) used when rot_flag != 0 (:161-185).
+ * mean / stdv: the 579-entry float64 statistics (zero std already replaced by 1).  Outputs: the reference's 7-tuple,
+ * each (B, T, n) contiguous fp32.  Source rows are clamped to [0, n_rows): validate descriptors on the host.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t row0;
+    int32_t stride;
+    int32_t reserved;
+    float rot[9];      /* row-major */
+    float pad_[3];
+} hmvae_clip;          /* 64 bytes */
+int hmvae_motion_batch(const float* frames, int64_t n_rows, const hmvae_clip* clips_dev, const double* mean,
+                       const double* stdv, int32_t B, int32_t T, int32_t rot_flag, float* r6, float* rmat, float* rot_pos,
+                       float* joint_pos, float* lin_v, float* ang_v, float* root_v, hmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Adam (torch.optim.Adam semantics: L2 weight decay folded into the gradient) — trainer_motion_vae.py:29-31, 92
  * One launch over a table of tensors; tensors whose gradient is absent are simply not listed.
  * ------------------------------------------------------------------------------------------------ */

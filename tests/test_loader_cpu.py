@@ -10,7 +10,7 @@ from helpers import ROOT
 
 
 def test_npy_loader_slices_and_standardisation(tmp_path):
-    from hm_vae_amd.utils_motion_vae import NpySequenceLoader, load_mean_std, get_train_loaders_all_data_seq
+    from hm_vae_amd.utils_motion_vae import NpySequenceLoader, load_mean_std
     rng = np.random.default_rng(0)
     seqs = []
     for i in range(5):
@@ -43,8 +43,6 @@ def test_npy_loader_slices_and_standardisation(tmp_path):
             assert np.allclose(tup[4][b].numpy(), n[:, 432:504], atol=1e-6)
             assert np.allclose(tup[5][b].numpy(), n[:, 504:576], atol=1e-6)
             assert np.allclose(tup[6][b].numpy(), n[:, 576:579], atol=1e-6)
-    tr, va, te = get_train_loaders_all_data_seq({"batch_size": B, "train_seq_len": T}, None, str(tmp_path))
-    assert next(iter(te))[0].shape[0] == 1
 
 
 def test_synthetic_loader_layout_cpu_only_for_vae():
@@ -52,3 +50,60 @@ def test_synthetic_loader_layout_cpu_only_for_vae():
     tr, va, te = get_train_loaders_all_data_seq({"batch_size": 3, "train_seq_len": 8, "model_name": "TrajectoryModel"},
                                                 torch.device("cpu"))
     assert tr.with_positions and len(tr) == 64 and te.B == 1
+
+
+def test_device_loader_host_sampler_follows_the_reference_rules():
+    """DeviceMotionLoader.sample_clip / describe (host side of hmvae_motion_batch): MotionSeqData's control flow
+    (utils_motion_vae.py:66-83, 124-141) -- strides from the fps list that leave >= T frames, crops inside the strided
+    sequence, too-short sequences replaced -- and descriptors that address the packed table."""
+    import pytest
+    from oracle import hmvae_oracle as O
+    from hm_vae_amd import _lib
+    from hm_vae_amd.utils_motion_vae import DeviceMotionDataset, DeviceMotionLoader, FPS_STRIDES, rand_rotation_matrix
+    seqs = O.synthetic_motion_files()
+    ds = DeviceMotionDataset(seqs, "cpu")
+    assert len(ds) == 4 and ds.n_rows == 30 + 47 + 200 + 12 and list(ds.seq_start) == [0, 30, 77, 277]
+    assert FPS_STRIDES == O.FPS_STRIDES
+    T = 16
+    ld = DeviceMotionLoader(ds, 2, T, fps_aug=True, root_rot=True, seed=1)
+    assert len(ld) == 2
+    strides = set()
+    for trial in range(300):
+        asked = trial % 4
+        seq, stride, crop, rot = ld.sample_clip(asked)
+        n2 = len(range(0, int(ds.seq_len[seq]), stride))
+        assert stride in FPS_STRIDES and n2 >= T and 0 <= crop <= n2 - T
+        assert seq == asked or ds.seq_len[asked] < T or len(range(0, int(ds.seq_len[asked]), 1)) < T
+        assert np.allclose(rot @ rot.T, np.eye(3), atol=1e-12)
+        strides.add(stride)
+        clip = ld.describe([(seq, stride, crop, rot)])[0]
+        assert clip["row0"] == ds.seq_start[seq] + crop * stride
+        assert clip["row0"] + (T - 1) * clip["stride"] < ds.seq_start[seq] + ds.seq_len[seq]
+    assert len(strides) > 3
+    # the vectorised batch sampler obeys the same rules
+    for fps_aug in (False, True):
+        ldb = DeviceMotionLoader(ds, 64, T, fps_aug=fps_aug, root_rot=True, seed=3)
+        asked = np.arange(64) % 4
+        seq, stride, crop, rot = ldb.sample_batch(asked)
+        n2 = -(-ds.seq_len[seq] // stride)
+        assert (n2 >= T).all() and (crop >= 0).all() and (crop <= n2 - T).all() and np.isin(stride, FPS_STRIDES).all()
+        assert ((seq == asked) | (ds.seq_len[asked] < T)).all() and (seq[asked != 3] == asked[asked != 3]).all()
+        assert fps_aug or (stride == 1).all()
+        assert np.allclose(rot @ rot.transpose(0, 2, 1), np.eye(3), atol=1e-12) and np.allclose(np.linalg.det(rot), 1.0)
+        clips = ldb.describe((seq, stride, crop, rot))
+        assert (clips["row0"] + (T - 1) * clips["stride"] < ds.seq_start[seq] + ds.seq_len[seq]).all()
+        one = ldb.describe([(int(seq[5]), int(stride[5]), int(crop[5]), rot[5])])[0]
+        assert one == clips[5]
+    u = np.array([0.3, 0.6, 0.9])
+    assert np.array_equal(rand_rotation_matrix(u), O.rand_rotation_from_uniforms(u))
+    # the 12-frame sequence can never be served at T = 16 without fps augmentation either
+    ld2 = DeviceMotionLoader(ds, 2, T, seed=2)
+    assert all(ld2.sample_clip(3)[0] != 3 for _ in range(20))
+    with pytest.raises(ValueError):
+        DeviceMotionLoader(ds, 2, 500)
+    with pytest.raises(ValueError):
+        bad = ld.describe([(2, 12, 0, None)])
+        bad["row0"] = ds.n_rows - 3
+        ds.assemble(bad, T, False)
+    with pytest.raises(_lib.HmvaeError):                      # no CPU path: the table must live on a HIP device
+        ds.assemble(ld.describe([ld.sample_clip(0)]), T, True)
