@@ -16,29 +16,45 @@ class GraphedStep:
         self.it = int(iterations)
         self.use_graph = bool(use_graph)
         dev = next(self.model.parameters()).device
+        self.is_vae = cfg['model_name'] == "TwoHierSAVAEModel"
         # static input buffers: the graph reads these addresses on every replay
-        self.r6 = data[0].to(device=dev, dtype=torch.float32).contiguous().clone()
-        self.rmat = data[1].to(device=dev, dtype=torch.float32).contiguous().clone()
-        self.data = (self.r6, self.rmat) + tuple(data[2:])
+        # (TrajectoryModel: its encoder input -- joint positions, or the 6D rotations -- and the root velocity)
+        self.slots = (0, 1) if self.is_vae else ((3 if cfg['trajectory_input_joint_pos'] else 0), 6)
+        self.r6 = data[self.slots[0]].to(device=dev, dtype=torch.float32).contiguous().clone()
+        self.rmat = data[self.slots[1]].to(device=dev, dtype=torch.float32).contiguous().clone()
+        lst = list(data)
+        lst[self.slots[0]], lst[self.slots[1]] = self.r6, self.rmat
+        self.data = tuple(lst)
         self.graphs = None
         self.g1b = None
         import os
         # HMVAE_DDP_SPLIT=0: one all-reduce after the whole backward.  HMVAE_FORCE_SPLIT=1: take the multi-graph path
         # on a single GPU too (tests / overhead measurement).
-        self.split = os.environ.get("HMVAE_DDP_SPLIT", "1") != "0"
+        self.split = os.environ.get("HMVAE_DDP_SPLIT", "1") != "0" and self.is_vae
         self.force_split = os.environ.get("HMVAE_FORCE_SPLIT", "0") == "1"
         self._pinned = None
         self.phase2 = None
         self.warmup = warmup
 
     def set_batch(self, data):
-        self.r6.copy_(data[0], non_blocking=True)
-        self.rmat.copy_(data[1], non_blocking=True)
+        self.r6.copy_(data[self.slots[0]], non_blocking=True)
+        self.rmat.copy_(data[self.slots[1]], non_blocking=True)
+
+    def _engine(self):
+        return self.model.engine() if self.is_vae else self.model.engine(self.r6.shape[1])
+
+    def _tuple(self, ls):
+        if self.is_vae:
+            return (ls[0], ls[1], ls[2], ls[3], ls[4], 0.0, 0.0, 0.0, 0.0)
+        return tuple(ls[:9])
 
     # -- the step body, split at the collectives --
     def _fwd_bwd(self):
-        eng = self.model.engine()
-        self.losses = eng.train_step(self.r6, self.rmat, self.it, eps_list=None, backward=True)
+        eng = self._engine()
+        if self.is_vae:
+            self.losses = eng.train_step(self.r6, self.rmat, self.it, eps_list=None, backward=True)
+        else:
+            self.losses = eng.train_step(self.r6, self.rmat, backward=True)
 
     def _fwd_bwd_dec(self):             # forward + the decoder's backward: every decoder gradient is final afterwards
         eng = self.model.engine()
@@ -52,7 +68,7 @@ class GraphedStep:
 
     def _reduce(self):
         if ddp.is_distributed():
-            eng = self.model.engine()
+            eng = self._engine()
             ddp.all_reduce_mean_(eng.flat_grad[:eng.active_grad_floats(self.phase2)])
 
     def _reduce_dec_async(self):
@@ -68,8 +84,11 @@ class GraphedStep:
         ddp.wait(handle)
         ddp.scale_(eng.flat_grad[:n])
 
+    def _phase2(self):
+        return self.is_vae and self.it >= self.cfg['iteration_interval']
+
     def _capture(self):
-        self.phase2 = self.it >= self.cfg['iteration_interval']
+        self.phase2 = self._phase2()
         # warm up eagerly on a side stream: creates workspaces, index tables and the Adam state outside the graph
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -122,7 +141,7 @@ class GraphedStep:
             out = self.tr.gen_update(self.data, self.cfg, self.it, False)
             self.it += 1
             return out
-        if self.graphs is None or self.phase2 != (self.it >= self.cfg['iteration_interval']):
+        if self.graphs is None or self.phase2 != self._phase2():
             self._capture()
         g1, g2 = self.graphs
         g1.replay()
@@ -142,10 +161,9 @@ class GraphedStep:
             opt.sync_lr()
         self.it += 1
         if not lag:
-            ls = self.losses.tolist()       # the step's only host synchronisation
-            return (ls[0], ls[1], ls[2], ls[3], ls[4], 0.0, 0.0, 0.0, 0.0)
+            return self._tuple(self.losses.tolist())       # the step's only host synchronisation
         if self._pinned is None:
-            self._pinned = [torch.empty(8, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._pinned = [torch.empty(self.losses.numel(), dtype=torch.float32).pin_memory() for _ in range(2)]
             self._events = [torch.cuda.Event(), torch.cuda.Event()]
             self._n_lag = 0
         k = self._n_lag & 1
@@ -154,10 +172,8 @@ class GraphedStep:
         self._n_lag += 1
         j = k if self._n_lag == 1 else 1 - k    # previous step's slot (this step's on the very first call)
         self._events[j].synchronize()
-        ls = self._pinned[j].tolist()
-        return (ls[0], ls[1], ls[2], ls[3], ls[4], 0.0, 0.0, 0.0, 0.0)
+        return self._tuple(self._pinned[j].tolist())
 
     def last_losses(self):
         """Blocking read of the most recent step's losses (after a run(lag=True) loop)."""
-        ls = self.losses.tolist()
-        return (ls[0], ls[1], ls[2], ls[3], ls[4], 0.0, 0.0, 0.0, 0.0)
+        return self._tuple(self.losses.tolist())

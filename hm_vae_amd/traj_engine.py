@@ -65,6 +65,7 @@ class TrajEngine(_StepBase):
         # fc_mapping over the frames: one "edge" that owns every latent channel, one tap, T positions
         self.head = ops.conv_gemm(device, [[0]], p.latent_ch, 3, 1, 1, 0, p.pad_mode, T, need_dx=True)
         self._ws = {}
+        self._multipack = None
         self.flops_per_seq = 2 * sum(op.useful_macs_per_col for op in self.conv + [self.head])
 
     # ------------------------------------------------------------------------------------------
@@ -135,9 +136,14 @@ class TrajEngine(_StepBase):
     def pack_weights(self):
         """Regather the dense weights into MFMA-fragment order (applies the neighbour mask, skeleton.py:96)."""
         enc_w, _ = self.names()
-        for i, op in enumerate(self.conv):
-            op.pack(self.params[enc_w[i]])
-        self.head.pack(self.params["fc_mapping.weight"].reshape(3, self.p.fc_in, 1))
+        if self._multipack is None:
+            self._multipack = ops.MultiPack(self.device)          # every layout of the model in one launch
+        lst = []
+        for op, wt in list(zip(self.conv, (self.params[n] for n in enc_w))) + [(self.head, self.params["fc_mapping.weight"])]:
+            lst.append((op.fwd, wt))
+            if op.bwd is not None:
+                lst.append((op.bwd, wt))
+        self._multipack.run(lst)
 
     # ------------------------------------------------------------------------------------------
     def encode(self, w, joint_pos):

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--graph", type=int, default=1, help="1: hipGraph replay of the step (GraphedStep), 0: eager launches")
     a = ap.parse_args()
     from hm_vae_amd.trainer_motion_vae import Trainer
     from hm_vae_amd.utils_common import get_config
@@ -34,17 +35,21 @@ def main():
     tr.cuda()
     T = cfg["train_seq_len"]
     batches = list(SyntheticMotionLoader(a.batch, T, dev, 4, 0, with_positions=True))
+    from hm_vae_amd.graph_step import GraphedStep
+    gs = GraphedStep(tr, cfg, batches[0], 0, use_graph=bool(a.graph))
     for i in range(a.warmup):
-        tr.gen_update(batches[i % 4], cfg, i, False)
+        gs.set_batch(batches[i % 4])
+        gs.run(lag=bool(a.graph))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        tr.gen_update(batches[i % 4], cfg, a.warmup + i, False)
+        gs.set_batch(batches[i % 4])
+        gs.run(lag=bool(a.graph))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    eng = tr.model.last_engine
+    eng = tr.model.engine(T)
     out = {"metric": "trajectory_train_sequences_per_sec", "value": a.batch / dt, "ms_per_step": dt * 1e3,
-           "batch": a.batch, "seq_len": T, "dtype": "f32",
+           "batch": a.batch, "seq_len": T, "dtype": "f32", "graph": bool(a.graph),
            "algorithmic_tflops": 3 * eng.flops_per_seq * a.batch / dt / 1e12}
     if a.cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
