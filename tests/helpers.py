@@ -14,8 +14,12 @@ CFG_FILES = {"len64": "len64_no_aug_hm_vae.yaml", "len8": "len8_data_aug_hm_vae.
 
 
 def load_cfg(tag):
-    with open(os.path.join(CONFIGS, CFG_FILES[tag])) as f:
-        return yaml.safe_load(f)
+    """len16: the len8 config at train_seq_len = 16 (the T == 16 branch of the reference's stride / upsampling ladders)."""
+    with open(os.path.join(CONFIGS, CFG_FILES["len8" if tag == "len16" else tag])) as f:
+        cfg = yaml.safe_load(f)
+    if tag == "len16":
+        cfg["train_seq_len"] = 16
+    return cfg
 
 
 def load_model_golden(tag):

@@ -11,7 +11,7 @@ from oracle import hmvae_oracle as O
 from helpers import GOLDEN, load_cfg, offsets
 
 
-@pytest.mark.parametrize("tag", ["len64", "len8"])
+@pytest.mark.parametrize("tag", ["len64", "len8", "len16"])
 def test_engine_plans_on_cpu(tag):
     from hm_vae_amd.trainer_motion_vae import Trainer
     from hm_vae_amd.engine import VaeEngine

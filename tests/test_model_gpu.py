@@ -43,7 +43,7 @@ def soa_to_bct(t, B, Cn, T):
     return out.reshape(B, Cn, T).cpu().numpy()
 
 
-@pytest.mark.parametrize("tag", ["len64", "len8"])
+@pytest.mark.parametrize("tag", ["len64", "len8", "len16"])
 @pytest.mark.parametrize("phase", ["p1", "p2"])
 def test_forward_backward_vs_reference_golden(dev, tag, phase):
     g, meta = load_model_golden(tag)
@@ -99,7 +99,7 @@ def test_forward_backward_vs_reference_golden(dev, tag, phase):
         assert float((gr * (1 - m)).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("tag", ["len64", "len8"])
+@pytest.mark.parametrize("tag", ["len64", "len8", "len16"])
 def test_validation_flag_leaves_grads_alone(dev, tag):
     g, meta = load_model_golden(tag)
     cfg, plan, tr, seeded = make_trainer(tag, dev)
@@ -110,7 +110,7 @@ def test_validation_flag_leaves_grads_alone(dev, tag):
     assert abs(float(tr.loss_val_total) - g["p1|losses"][0]) < TOL * abs(g["p1|losses"][0])
 
 
-@pytest.mark.parametrize("tag", ["len64", "len8"])
+@pytest.mark.parametrize("tag", ["len64", "len8", "len16"])
 def test_two_trainer_steps_vs_reference(dev, tag):
     g, meta = load_model_golden(tag)
     cfg, plan, tr, seeded = make_trainer(tag, dev)
@@ -142,7 +142,7 @@ def test_two_trainer_steps_vs_reference(dev, tag):
         assert n in names
 
 
-@pytest.mark.parametrize("tag", ["len64", "len8"])
+@pytest.mark.parametrize("tag", ["len64", "len8", "len16"])
 def test_decoder_only_sampling_vs_reference(dev, tag):
     """BASELINE config 4 semantics: z-list -> _decode -> (6D, R, joint positions), seeded weights."""
     g, meta = load_model_golden(tag)

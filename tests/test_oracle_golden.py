@@ -111,7 +111,7 @@ def _oracle(tag):
     return cfg, plan, m
 
 
-@pytest.mark.parametrize("tag", ["len64", "len8"])
+@pytest.mark.parametrize("tag", ["len64", "len8", "len16"])
 def test_constants_and_state_dict_layout(tag):
     g, meta = load_model_golden(tag)
     cfg, plan, m = _oracle(tag)
@@ -135,7 +135,7 @@ def test_constants_and_state_dict_layout(tag):
     assert len(meta["trainable_order"]) == 30
 
 
-@pytest.mark.parametrize("tag", ["len64", "len8"])
+@pytest.mark.parametrize("tag", ["len64", "len8", "len16"])
 @pytest.mark.parametrize("phase", ["p1", "p2"])
 def test_train_forward_backward_matches_reference(tag, phase):
     g, meta = load_model_golden(tag)
@@ -169,7 +169,7 @@ def test_train_forward_backward_matches_reference(tag, phase):
     assert len(none) == (10 if phase == "p1" else 8)
 
 
-@pytest.mark.parametrize("tag", ["len64", "len8"])
+@pytest.mark.parametrize("tag", ["len64", "len8", "len16"])
 def test_two_adam_steps_match_reference_trainer(tag):
     g, meta = load_model_golden(tag)
     cfg, plan, m = _oracle(tag)
@@ -195,7 +195,7 @@ def test_two_adam_steps_match_reference_trainer(tag):
     assert abs(opt.param_groups[0]["lr"] - meta["lr_after_2"]) < 1e-12
 
 
-@pytest.mark.parametrize("tag", ["len64", "len8"])
+@pytest.mark.parametrize("tag", ["len64", "len8", "len16"])
 def test_decoder_only_sampling_matches_reference(tag):
     g, meta = load_model_golden(tag)
     cfg, plan, m = _oracle(tag)

@@ -100,9 +100,11 @@ def fk_rot_golden(ref_tools, ref_fk_mod):
                 anchor_d6=xa.grad.numpy(), rest=rest.numpy())
 
 
-def model_golden(cfg_name, B, seed):
+def model_golden(cfg_name, B, seed, seq_len=None):
     import trainer_motion_vae as RT
     cfg = yaml.safe_load(open(os.path.join(H.REF_ROOT, "configs", cfg_name)))
+    if seq_len is not None:                 # the T == 16 branch of the stride / upsampling ladders (:79-90, :107-118)
+        cfg["train_seq_len"] = seq_len
     plan = O.Plan(cfg)
     tr = RT.Trainer(cfg)
     model = tr.model
@@ -290,19 +292,28 @@ def traj_golden(B, T, seed):
     return store, meta
 
 
-def vae_fixtures():
+def vae_fixtures(only=None):
     import skeleton as ref_skel
     import my_tools as ref_tools
     import fk_layer as ref_fk_mod
-    topo = topology_dump(ref_skel, os.path.join(H.REF_ROOT, "utils/data/joint24_parents.json"))
-    json.dump(topo, open(os.path.join(OUT, "topology.json"), "w"))
-    np.savez_compressed(os.path.join(OUT, "fk_rot6d.npz"), **fk_rot_golden(ref_tools, ref_fk_mod))
+    if only is None:
+        topo = topology_dump(ref_skel, os.path.join(H.REF_ROOT, "utils/data/joint24_parents.json"))
+        json.dump(topo, open(os.path.join(OUT, "topology.json"), "w"))
+        np.savez_compressed(os.path.join(OUT, "fk_rot6d.npz"), **fk_rot_golden(ref_tools, ref_fk_mod))
     metas = {}
-    for tag, cfg, B, seed in (("len64", "len64_no_aug_hm_vae.yaml", 2, 11), ("len8", "len8_data_aug_hm_vae.yaml", 4, 21)):
-        store, meta = model_golden(cfg, B, seed)
+    for tag, cfg, B, seed, T in (("len64", "len64_no_aug_hm_vae.yaml", 2, 11, None), ("len8", "len8_data_aug_hm_vae.yaml", 4, 21, None),
+                                 ("len16", "len8_data_aug_hm_vae.yaml", 3, 51, 16)):
+        if only is not None and tag != only:
+            continue
+        store, meta = model_golden(cfg, B, seed, T)
         np.savez_compressed(os.path.join(OUT, "model_%s.npz" % tag), **store)
         metas[tag] = meta
-    json.dump(metas, open(os.path.join(OUT, "model_meta.json"), "w"), indent=1)
+    mp = os.path.join(OUT, "model_meta.json")
+    if only is not None and os.path.exists(mp):
+        old = json.load(open(mp))
+        old.update(metas)
+        metas = old
+    json.dump(metas, open(mp, "w"), indent=1)
 
 
 def loader_golden():
@@ -384,6 +395,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if only_loader:
         loader_golden()
+        return
+    if "--len16-only" in sys.argv:
+        import skeleton, my_tools, fk_layer  # noqa: F401  (same import order as the full run)
+        vae_fixtures(only="len16")
         return
     if not only_traj:
         vae_fixtures()
