@@ -605,9 +605,9 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     return v;
 }
 
-// One workgroup = TL_FRAMES frames x 4 waves (lanes >= TL_FRAMES idle).  The kernel is latency-bound -- every joint step
-// waits for its own loads -- so at the 16 384 frames of the training step 32-frame workgroups (two per CU) run the same
-// dependent chain twice as often in parallel as 64-frame ones (one per CU).
+// One workgroup = TL_FRAMES frames x 4 waves.  TL_FRAMES = 32 (half-empty waves, two workgroups per CU at the 16 384
+// frames of the training step) was measured at 62 us against 35 us for 64: the kernel is bound by vector-instruction
+// issue, not by the latency of its loads, and half-empty waves double the instructions per frame.
 // A frame's work is split by SUBTREE over the waves (a wave runs one role, so
 // there is no divergence and every load/store stays a 256-byte row segment): one thread per frame left 3 of 4 SIMDs
 // without a wave at the 16 384 frames of the training step and ran ~120 us on the critical path.
@@ -616,7 +616,7 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 //   wave 0: the head (subtree of 12), then -- after one barrier -- the trunk 9 -> 6 -> 3 -> 0 with the limbs' sums
 // Every wave recomputes the trunk's forward chain it needs (<= 4 lifts + 3 products); a limb hands its parent
 // S = sum of dP over the subtree and H = H_c R_c^T + S (x) off_c through LDS (12 floats per frame).
-constexpr int TL_FRAMES = 32;
+constexpr int TL_FRAMES = 64;
 __global__ __launch_bounds__(256) void decode_tail_loss_kernel(const float* __restrict__ dec, const float* __restrict__ g6,
                                                                const float* __restrict__ gR, const float* __restrict__ gP,
                                                                const float* __restrict__ offs, int T, int B, int bp,

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--seq-len", type=int, default=0, help="override train_seq_len (BASELINE config 5 quotes len-64)")
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="1: hipGraph replay of the step (GraphedStep), 0: eager launches")
     a = ap.parse_args()
@@ -30,6 +31,8 @@ def main():
     from hm_vae_amd.utils_motion_vae import SyntheticMotionLoader
     cfg = get_config(os.path.join(ROOT, "configs", "trajectory_model.yaml"))
     cfg["batch_size"] = a.batch
+    if a.seq_len:
+        cfg["train_seq_len"] = a.seq_len
     dev = torch.device("cuda:0")
     tr = Trainer(cfg)
     tr.cuda()

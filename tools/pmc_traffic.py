@@ -23,10 +23,15 @@ def short(name):
     return name.split("(")[0].split("<")[0].strip()
 
 
+def newest(pattern):
+    """gpurun merges new files into gpurun_out/ without removing those of earlier calls: take the latest run only."""
+    files = glob.glob(pattern, recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def collect(sub, counter):
     out = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(root, "gpurun_out", "prof_%s_%s" % (tag, sub), "**", "*counter_collection.csv"),
-                       recursive=True):
+    for f in newest(os.path.join(root, "gpurun_out", "prof_%s_%s" % (tag, sub), "**", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 out[short(r["Kernel_Name"])].append(float(r["Counter_Value"]) * 1024.0)
@@ -45,9 +50,9 @@ os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 json.dump({"tag": tag, "unit": "bytes per launch (mean over all launches of the kernel in the run)",
            "correction": "FETCH_SIZE*1024*2 (gfx950 half-count), WRITE_SIZE*1024", "kernels": res},
           open(os.path.join(root, "profiles", "%s_traffic.json" % tag), "w"), indent=1)
-for f in glob.glob(os.path.join(root, "gpurun_out", "prof_%s_stats" % tag, "**", "*kernel_stats.csv"), recursive=True):
+for f in newest(os.path.join(root, "gpurun_out", "prof_%s_stats" % tag, "**", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(root, "profiles", "%s_kernel_stats.csv" % tag))
-for f in glob.glob(os.path.join(root, "gpurun_out", "prof_%s_serial" % tag, "**", "*kernel_stats.csv"), recursive=True):
+for f in newest(os.path.join(root, "gpurun_out", "prof_%s_serial" % tag, "**", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(root, "profiles", "%s_serial_kernel_stats.csv" % tag))
 for k, v in res.items():
     print("%-40s fetch(x2) %10.3f MB  write %10.3f MB  n=%d" % (k[:40], v["fetch_bytes_x2"] / 1e6, v["write_bytes"] / 1e6,
