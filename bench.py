@@ -230,7 +230,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     _lib.require_gpu()
-    device = torch.device("cuda", local if world > 1 else 0)
+    # HMVAE_SINGLE_DEVICE=1 (with HMVAE_DIST_BACKEND=gloo): every rank on cuda:0 -- a control-flow rehearsal of the N > 1
+    # launch on a one-GPU box, not a measurement
+    one_dev = os.environ.get("HMVAE_SINGLE_DEVICE", "0") == "1"
+    device = torch.device("cuda", local if (world > 1 and not one_dev) else 0)
     torch.cuda.set_device(device)
     cfg = get_config(args.config)
     torch.manual_seed(1234)
@@ -276,7 +279,9 @@ def main():
                       "loss_readback": "every step, lagging one step (non-blocking)" if lag else "every step, blocking"},
            "loss_total": float(step.last_losses()[0]) if lag else float(losses[0])}
 
-    if rank == 0 and not args.no_kernel_timing:
+    # N = 1 only: the extra eager steps below go through Trainer.gen_update, whose gradient all-reduce is a collective --
+    # rank 0 alone must not enter it
+    if rank == 0 and world == 1 and not args.no_kernel_timing:
         # instrumented extra steps (eager, same workload): per-launch HIP events around every MFMA kernel
         eng = tr.model.engine()
         timer = KernelTimer()
@@ -314,7 +319,7 @@ def main():
         out["roofline"]["step_level"] = {"conv_flops_per_step_effective": conv_flops_step,
                                          "achieved_TFLOP/s": conv_flops_step / (ms_per_step * 1e-3) / 1e12,
                                          "frac": conv_flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
-    if rank == 0 and not args.no_fk:
+    if rank == 0 and world == 1 and not args.no_fk:
         out["fk_roofline"] = fk_microbench(device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg)

@@ -271,3 +271,31 @@ def test_graph_replay_split_path_matches_single_graph(dev, monkeypatch):
     assert rel_err(outs[1][0][:, :5], outs[0][0][:, :5]) < 5e-4
     frac_close = float((np.abs(outs[1][1] - outs[0][1]) < 1e-5).mean())
     assert frac_close > 0.999, frac_close
+
+
+def test_bench_two_rank_launch_rehearsal(dev, tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed on ONE GPU:
+    gloo instead of RCCL and both ranks on cuda:0 (HMVAE_DIST_BACKEND / HMVAE_SINGLE_DEVICE).  Exercises the parameter
+    broadcast, the three-graph step with the asynchronous decoder all-reduce, barriers, the MAX-over-ranks timing and a
+    clean exit of both ranks -- not a measurement."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HMVAE_DIST_BACKEND="gloo", HMVAE_SINGLE_DEVICE="1", HMVAE_TUNE_CACHE=str(tmp_path / "tune.json"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--batch", "64"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["scaling"] == "weak"
+    assert out["value"] > 0 and np.isfinite(out["loss_total"]) and "roofline" not in out
