@@ -657,6 +657,46 @@ extern "C" int hmvae_motion_batch(const float* frames, int64_t n_rows, const hmv
     return LAUNCH_OK();
 }
 
+// ---------------- exact three-way bf16 split (operand planes of the bf16x3 weight-gradient GEMM) ----------------
+// p0 = top 16 bits of x; r = x - p0 (exact); p1 = top 16 bits of r; p2 = top 16 bits of r - p1 (exact: <= 8 bits left)
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ x, uint16_t* __restrict__ planes,
+                                                           long long n8, long long plane_stride) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const float4 a = ((const float4*)x)[2 * i], b = ((const float4*)x)[2 * i + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned hb = __float_as_uint(v[k]) & 0xffff0000u;
+        const float r = v[k] - __uint_as_float(hb);
+        const unsigned mb = __float_as_uint(r) & 0xffff0000u;
+        const float r2 = r - __uint_as_float(mb);
+        h[k] = hb;
+        m[k] = mb;
+        l[k] = __float_as_uint(r2) & 0xffff0000u;
+    }
+    auto pack = [](const unsigned* w) {
+        uint4 o;
+        o.x = (w[0] >> 16) | w[1];
+        o.y = (w[2] >> 16) | w[3];
+        o.z = (w[4] >> 16) | w[5];
+        o.w = (w[6] >> 16) | w[7];
+        return o;
+    };
+    *(uint4*)(planes + 8 * i) = pack(h);
+    *(uint4*)(planes + plane_stride + 8 * i) = pack(m);
+    *(uint4*)(planes + 2 * plane_stride + 8 * i) = pack(l);
+}
+
+extern "C" int hmvae_split_bf16x3(const float* x, uint16_t* planes, int64_t n, int64_t plane_stride, hmvae_stream_t stream) {
+    if (!x || !planes || n <= 0 || (n & 7) || plane_stride < n || (plane_stride & 7)) return HMVAE_ERR_ARG;
+    const long long n8 = n >> 3;
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, planes,
+                       n8, (long long)plane_stride);
+    return LAUNCH_OK();
+}
+
 // ---------------- Adam ----------------
 __global__ __launch_bounds__(256) void adam_kernel(const hmvae_adam_tensor* __restrict__ tab,
                                                     const float* __restrict__ lr_dev, const int* __restrict__ step_dev,

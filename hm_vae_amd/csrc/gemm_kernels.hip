@@ -13,9 +13,11 @@
 // tile are permuted (MFMA tile j, column n  <->  batch column 4n+j) so that one 16-byte load per lane
 // feeds all four 16-column MFMA tiles and the epilogue stores 16 bytes per lane.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "hmvae.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -184,7 +186,12 @@ extern "C" int hmvae_gather_gemm(const hmvae_gemm_desc* desc, hmvae_stream_t str
 // K permutation: MFMA k-step j of a 16-batch block uses batch elements {4*kk + j}, so each lane feeds
 // four k-steps from one 16-byte load on both operands.
 // ------------------------------------------------------------------------------------------------
-template <int MT, bool ZP>
+// BF: the operands are read as THREE bf16 planes per tensor (hmvae_split_bf16x3: x = p0 + p1 + p2 exactly) and a chunk's
+// 32 batch columns go through v_mfma_f32_16x16x32_bf16 -- six products per tile (the cross terms down to 2^-16; what is
+// dropped is below 2^-23 of the product, one fp32 rounding) in 6 x 16 issue cycles where the fp32 instruction needs
+// 8 x 32 for the same K.  Same lane maps on both sides (lane (n, kk) holds 8 consecutive batch elements of row / column
+// n; the C/D layout does not depend on the input type), so everything outside load / fma is shared.
+template <int MT, bool ZP, bool BF>
 __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
     // LDS: first the per-position activation offset table (during the reduction loop), then the cross-wave sums
     extern __shared__ __attribute__((aligned(16))) float red[];
@@ -297,10 +304,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
     const char* __restrict__ xb = (const char*)(TR ? d.dz : d.x);        // column operand
     const unsigned dz_tstep = (unsigned)(TR ? d.x_ts : d.dz_ts) * (unsigned)bp * 4u;
     const int pad = d.pad, tsrc = d.t_src;
-    struct Ops {
+    struct OpsF {
         f32x4 a[MT][2];
         f32x4 b[4][2];
     };
+    struct OpsB {
+        bf16x8 a[MT][3];
+        bf16x8 b[4][3];
+    };
+    using Ops = std::conditional_t<BF, OpsB, OpsF>;
+    // plane addressing: element offsets are the fp32 ones, so byte offsets halve
+    const char* __restrict__ dzp = (const char*)(TR ? d.x_planes : d.dz_planes);
+    const char* __restrict__ xp = (const char*)(TR ? d.dz_planes : d.x_planes);
+    const size_t dz_ps = (size_t)(TR ? d.x_plane_stride : d.dz_plane_stride) * 2, x_ps = (size_t)(TR ? d.dz_plane_stride : d.x_plane_stride) * 2;
     auto load = [&](Ops& o, int chunk) {
         const int bb = chunk / T;            // scalar
         const int t = chunk - bb * T;
@@ -310,6 +326,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
             tr = tr < 0 ? -tr : tr;
             tr = tr >= tsrc ? 2 * (tsrc - 1) - tr : tr;
         }
+        if constexpr (BF) {
+            const char* dzs = dzp + (((size_t)tr * dz_tstep) >> 1) + (size_t)(bb << 6);
+            const char* xs = xp + (size_t)(bb << 6);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) o.a[mt][pl] = *(const bf16x8*)(dzs + pl * dz_ps + (rowbyte[mt] >> 1));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const unsigned e = xtab[t * 64 + nt * 16 + n];
+                const bool ok = !ZP || e != 0xffffffffu;
+                const unsigned off = ((ok ? e : 0u) + kk32) >> 1;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const bf16x8 v = *(const bf16x8*)(xs + pl * x_ps + off);
+                    if (ZP) {
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        o.b[nt][pl] = ok ? v : __builtin_bit_cast(bf16x8, z);
+                    } else {
+                        o.b[nt][pl] = v;
+                    }
+                }
+            }
+        } else {
         const char* dzs = dzb + (size_t)tr * dz_tstep + (size_t)(bb << 7);     // uniform base for this chunk
         const char* xs = xb + (size_t)(bb << 7);
 #pragma unroll
@@ -332,8 +372,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
                 o.b[nt][1] = *(const f32x4*)(xs + off + 16);
             }
         }
+        }
     };
     auto fma = [&](const Ops& o) {
+        if constexpr (BF) {
+            // smallest cross terms first: (0,2) (2,0) (1,1) | (0,1) (1,0) | (0,0)
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o.a[mt][PA[q]], o.b[nt][PB[q]], acc[mt][nt], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -342,6 +394,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(o.a[mt][h][j], o.b[nt][h][j], acc[mt][nt]);
+        }
     };
     auto flush = [&]() {
 #pragma unroll
@@ -365,11 +418,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(hmvae_wgrad_desc d) {
         for (int pb = 0; pb < pairs; pb += FLUSH_PAIRS) {
             const int pe = pb + FLUSH_PAIRS < pairs ? pb + FLUSH_PAIRS : pairs;
             for (int pi = pb; pi < pe; ++pi) {
+                // The scheduling barriers keep each prefetch AHEAD of the MFMA block it hides behind.  Left alone the
+                // compiler sinks the loads into the second half of that block: the next block then waits for loads
+                // issued ~50 MFMAs (1 500 cycles) earlier, less than a loaded memory round trip, and with one wave per
+                // SIMD (MT = 3: 268 registers) nothing else fills the stall.
                 load(o1, c + 4);
+                __builtin_amdgcn_sched_barrier(0);
                 fma(o0);
+                __builtin_amdgcn_sched_barrier(0);
                 const int nxt = c + 8 <= last ? c + 8 : last;      // clamped over-fetch at the tail
                 load(o0, nxt);
+                __builtin_amdgcn_sched_barrier(0);
                 fma(o1);
+                __builtin_amdgcn_sched_barrier(0);
                 c += 8;
             }
             flush();
@@ -410,12 +471,19 @@ static void launch_wgrad(const hmvae_wgrad_desc* d, dim3 grid, hipStream_t s) {
     const int npos = d->transposed ? d->t_src + 2 * d->pad : d->t_dst;
     const size_t tab2 = (size_t)npos * 64 * sizeof(unsigned);
     if (tab2 > lds) lds = tab2;
-    if (d->pad_mode == HMVAE_PAD_ZEROS || d->transposed) hipLaunchKernelGGL((wgrad_kernel<MT, true>), grid, dim3(256), lds, s, *d);
-    else hipLaunchKernelGGL((wgrad_kernel<MT, false>), grid, dim3(256), lds, s, *d);
+    const bool zp = d->pad_mode == HMVAE_PAD_ZEROS || d->transposed;
+    if (d->dz_planes) {
+        if (zp) hipLaunchKernelGGL((wgrad_kernel<MT, true, true>), grid, dim3(256), lds, s, *d);
+        else hipLaunchKernelGGL((wgrad_kernel<MT, false, true>), grid, dim3(256), lds, s, *d);
+    } else {
+        if (zp) hipLaunchKernelGGL((wgrad_kernel<MT, true, false>), grid, dim3(256), lds, s, *d);
+        else hipLaunchKernelGGL((wgrad_kernel<MT, false, false>), grid, dim3(256), lds, s, *d);
+    }
 }
 
 extern "C" int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream) {
     if (!desc || !desc->dz || !desc->x || !desc->slab) return HMVAE_ERR_ARG;
+    if ((desc->dz_planes == nullptr) != (desc->x_planes == nullptr)) return HMVAE_ERR_ARG;
     if (desc->bp <= 0 || (desc->bp & 63) || desc->n_tiles <= 0 || desc->n_split <= 0 || desc->kt <= 0) return HMVAE_ERR_ARG;
     if (desc->pad_mode == HMVAE_PAD_REFLECT && desc->pad >= desc->t_src && desc->pad > 0) return HMVAE_ERR_ARG;
     const long long nblk = desc->n_workers > 0 ? desc->n_workers : (long long)desc->n_tiles * desc->n_split;

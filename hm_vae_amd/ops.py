@@ -21,6 +21,12 @@ AUTOTUNE = _os.environ.get("HMVAE_AUTOTUNE", "1") != "0"
 FOLD = _os.environ.get("HMVAE_FOLD", "1") != "0"        # tap folding for convolutions over fewer positions than taps
 USE_V3 = _os.environ.get("HMVAE_V3", "1") != "0"
 WGRAD_PERSISTENT = _os.environ.get("HMVAE_WGRAD_PERSISTENT", "1") != "0"   # let the autotuner consider the persistent launch        # let the autotuner consider the v3 window kernel
+# Weight-gradient GEMM on the bf16 matrix pipe through exact three-way bf16 operand planes (hmvae.h, hmvae_wgrad_desc):
+# "0" never (default), "1" always, "auto" lets the autotuner time it against the fp32 MFMA per layer.  Measured on MI355X
+# (tools/wgrad_bf.py, B=256): fp32-grade results (4e-7 from the fp32 MFMA path) but 1.4x SLOWER -- the kernel streams every
+# operand fragment from L2 per wave (~20 B/cycle/CU, its real ceiling), and the planes are 1.5x the bytes; the 2.7x
+# shorter MFMA time only pays once the operands are shared through LDS (what comes next).
+WGRAD_BF16X3 = _os.environ.get("HMVAE_WGRAD_BF16X3", "0")
 # optional JSON file that persists the autotuner's choices between processes (profiling runs reuse it so the trace
 # holds only the launches of the timed steps)
 TUNE_CACHE = _os.environ.get("HMVAE_TUNE_CACHE")
@@ -479,6 +485,8 @@ class MaskedGemm:
         self.wg_transposed = False
         self._wg_sched = {}
         self._split_tuned = {}
+        self._bf_tuned = {}
+        self._plane_buf = {}
         self._ev_f = self._ev_b = None
         ge = self.geom
         if (self.bwd is not None and not self.folded and ge["stride"] == 1 and ge["pad_mode"] == _lib.PAD_REFLECT
@@ -550,6 +558,28 @@ class MaskedGemm:
     def persistent(self, bp):
         return self._split_tuned.get(bp) == "p"
 
+    def use_bf(self, bp):
+        if WGRAD_BF16X3 in ("0", "1"):
+            return WGRAD_BF16X3 == "1"
+        return bool(self._bf_tuned.get(bp, False))
+
+    def _planes(self, role, t):
+        """The three bf16 planes of operand tensor `t` (split on the current stream into this op's scratch)."""
+        n = t.numel()
+        key = (role, n)
+        buf = self._plane_buf.get(key)
+        if buf is None:
+            buf = self._plane_buf[key] = torch.empty(3 * n, dtype=torch.int16, device=t.device)
+        _lib.check(_lib.load().hmvae_split_bf16x3(_lib.ptr(t), buf.data_ptr(), n, n, _lib.stream()), "split_bf16x3")
+        return buf, n
+
+    def _plane_args(self, dy, x, bp):
+        if not self.use_bf(bp):
+            return (None, None, 0, 0)
+        pd, nd = self._planes("dz", dy)
+        px, nx = self._planes("x", x)
+        return (pd.data_ptr(), px.data_ptr(), nd, nx)
+
     def wg_schedule(self, bp):
         """Persistent weight-gradient launch: (CUs x resident workgroups) workers with equal numbers of reduction chunks
         (planner.build_stream_schedule over the tiles), as device tables."""
@@ -587,11 +617,12 @@ class MaskedGemm:
     def autotune_split(self, dy, x, dw, bp, slab):
         if bp in self._split_tuned or not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return
-        ck = "wg_t%d_m%d_k%d_c%d_tr%d_b%d" % (self.n_tiles_t if self.wg_transposed else self.n_tiles, self.wg.mt, self.kt,
-                                             self._k_chunks(bp), int(self.wg_transposed), bp)
+        ck = "wg3_t%d_m%d_k%d_c%d_tr%d_b%d" % (self.n_tiles_t if self.wg_transposed else self.n_tiles, self.wg.mt, self.kt,
+                                              self._k_chunks(bp), int(self.wg_transposed), bp)
         hit = _tune_cache_get(ck)
         if hit is not None:
             self._split_tuned[bp] = "p" if hit[0] == "p" else int(hit[0])
+            self._bf_tuned[bp] = bool(hit[1]) if len(hit) > 1 else False
             return
         scratch = torch.empty_like(dw)
         best = None
@@ -599,18 +630,22 @@ class MaskedGemm:
         cands = list(self.split_candidates(bp))
         if WGRAD_PERSISTENT and self._k_chunks(bp) >= 8:
             cands.append("p")
-        for c in cands:
-            self._split_tuned[bp] = c
+        modes = [False, True] if WGRAD_BF16X3 == "auto" else [WGRAD_BF16X3 == "1"]
+        for bf in modes:
+            self._bf_tuned[bp] = bf
+            for c in cands:
+                self._split_tuned[bp] = c
 
-            def once():
-                self.wgrad_gemm(dy, x, bp, slab)
-                r = self.reduce_desc(slab, scratch, bp, False)
-                _lib.check(_lib.load().hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce")
-            t = self.fwd._time(once)
-            if best is None or t < best[0]:
-                best = (t, c)
+                def once():
+                    self.wgrad_gemm(dy, x, bp, slab)             # includes the operand split in bf mode
+                    r = self.reduce_desc(slab, scratch, bp, False)
+                    _lib.check(_lib.load().hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce")
+                t = self.fwd._time(once)
+                if best is None or t < best[0]:
+                    best = (t, c, bf)
         self._split_tuned[bp] = best[1]
-        _tune_cache_put(ck, (best[1],))
+        self._bf_tuned[bp] = best[2]
+        _tune_cache_put(ck, (best[1], int(best[2])))
 
     def backward_weight(self, dy, x, dw, bp, slab, accumulate=False):
         self.autotune_split(dy, x, dw, bp, slab)
@@ -659,7 +694,8 @@ class MaskedGemm:
         d = _lib.WgradDesc(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(slab), _lib.ptr(self.tile_g), _lib.ptr(self.tile_col0),
                            _lib.ptr(self.g_ncols), _lib.ptr(tb["g_choff"]), _lib.ptr(self.wg_chan_rows),
                            _lib.ptr(self.dz_rows), self.n_tiles, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"],
-                           ge["stride"], ge["pad"], ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 0, *self._wg_items(bp))
+                           ge["stride"], ge["pad"], ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 0, *self._wg_items(bp),
+                           *self._plane_args(dy, x, bp))
         _lib.check(lib.hmvae_wgrad_gemm(C.byref(d), _lib.stream()), "wgrad_gemm")
 
     def _wg_items(self, bp):
@@ -686,7 +722,7 @@ def _mg_wgrad_gemm_t(self, dy, x, bp, slab):
     d = _lib.WgradDesc(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(slab), _lib.ptr(self.tile_g_t), _lib.ptr(self.tile_col0_t),
                        _lib.ptr(self.g_ncols_t), _lib.ptr(b.g_choff), _lib.ptr(b.chan_rows), _lib.ptr(b.dst_rows),
                        self.n_tiles_t, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"], ge["stride"], ge["pad"],
-                       ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 1, *self._wg_items(bp))
+                       ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 1, *self._wg_items(bp), *self._plane_args(dy, x, bp))
     _lib.check(lib.hmvae_wgrad_gemm(C.byref(d), _lib.stream()), "wgrad_gemm(T)")
 
 

@@ -184,9 +184,20 @@ typedef struct {
     const int32_t* items;
     const int32_t* worker_items;
     int32_t n_workers, pad_;
+    /* Optional: both operands as three bf16 planes each (hmvae_split_bf16x3: value = plane0 + plane1 + plane2 exactly),
+     * plane p of element i at planes[p * plane_stride + i], same element indexing as dz / x.  When dz_planes is given the
+     * products run on the bf16 matrix pipe as six cross terms per fp32 product (everything above 2^-23 of it), fp32
+     * accumulation: fp32-grade results at 3/8 of the fp32 MFMA issue cycles.  NULL: plain fp32 MFMA on dz / x. */
+    const uint16_t* dz_planes;
+    const uint16_t* x_planes;
+    int64_t dz_plane_stride, x_plane_stride;
 } hmvae_wgrad_desc;
 
 int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream);
+
+/* x[i] -> planes[p * plane_stride + i], p = 0..2: the exact three-way bf16 split of an fp32 tensor (truncations of the
+ * running remainder: 8 + 8 + 8 significand bits), n a multiple of 8. */
+int hmvae_split_bf16x3(const float* x, uint16_t* planes, int64_t n, int64_t plane_stride, hmvae_stream_t stream);
 
 /* dense[row_out[g,r]*row_stride + chan_id[c]*chan_stride + tap] (+)= sum_s slab[s][tile][r][col] */
 typedef struct {

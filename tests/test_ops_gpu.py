@@ -482,3 +482,37 @@ def test_adam_matches_torch(dev):
                                                step_dev.data_ptr(), 0.9, 0.999, 1e-8, 1e-4, _lib.stream()), "adam")
     for r, d in zip(ref, dp):
         assert rel_err(d.cpu().numpy(), r.detach().numpy()) < 1e-5
+
+
+def test_wgrad_bf16x3_planes_match_fp32_path(dev, monkeypatch):
+    """hmvae_split_bf16x3 is an exact split (p0 + p1 + p2 == x bit for bit) and the weight-gradient GEMM fed with the
+    planes (six bf16 MFMA cross terms per product, fp32 accumulation) agrees with the fp32-MFMA path to fp32 rounding."""
+    import ctypes as C
+    from hm_vae_amd import ops, _lib
+    x = torch.randn(4096 * 8, device=dev) * torch.logspace(-6, 6, 4096 * 8, device=dev)
+    x[:16] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1e-25, 1e-30, 0.1, 1 / 3, 65504.0, 2 ** -20, 7.0, -7.5, 1e10, -1e-10])
+    planes = torch.empty(3 * x.numel(), dtype=torch.int16, device=dev)
+    _lib.check(_lib.load().hmvae_split_bf16x3(_lib.ptr(x), planes.data_ptr(), x.numel(), x.numel(), _lib.stream()), "split")
+    p = planes.view(3, -1).to(torch.int32)
+    parts = ((p & 0xffff) << 16).view(torch.float32)          # bf16 bits -> fp32
+    back = (parts[0].double() + parts[1].double() + parts[2].double()).float()
+    bad = (back != x).nonzero().reshape(-1)
+    assert bad.numel() == 0, (x[bad[:8]], back[bad[:8]])        # (remainders below 2^-126 would flush: not in this range)
+    # a masked conv's weight gradient both ways
+    neigh = [[0, 1], [0, 1, 2], [1, 2, 3], [2, 3]]
+    op = ops.conv_gemm(dev, neigh, 4 * 6, 4 * 12, 15, 1, 7, "reflect", 32, need_dx=True)
+    B = 70
+    bp = ops.pad_batch(B)
+    xa = torch.zeros(24 * 32, bp, device=dev)
+    dy = torch.zeros(48 * 32, bp, device=dev)
+    xa[:, :B] = torch.randn(24 * 32, B, device=dev)
+    dy[:, :B] = torch.randn(48 * 32, B, device=dev)
+    slab = torch.empty(op.slab_floats(bp), device=dev)
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setattr(ops, "WGRAD_BF16X3", mode)
+        dw = torch.zeros(48, 24, 15, device=dev)
+        op.backward_weight(dy, xa, dw, bp, slab)
+        outs.append(dw)
+    assert float(outs[0].abs().max()) > 0
+    assert rel_err(outs[1].cpu().numpy(), outs[0].cpu().numpy()) < 2e-6
