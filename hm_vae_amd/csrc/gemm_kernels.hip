@@ -481,6 +481,8 @@ static void launch_wgrad(const hmvae_wgrad_desc* d, dim3 grid, hipStream_t s) {
     }
 }
 
+int hmvae_wgrad_lds_launch(const hmvae_wgrad_desc* d, unsigned grid, hipStream_t s);      // wgrad_lds.hip
+
 extern "C" int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream) {
     if (!desc || !desc->dz || !desc->x || !desc->slab) return HMVAE_ERR_ARG;
     if ((desc->dz_planes == nullptr) != (desc->x_planes == nullptr)) return HMVAE_ERR_ARG;
@@ -497,6 +499,11 @@ extern "C" int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t str
     }
     dim3 grid((unsigned)(((nblk + 7) / 8) * 8));
     hipStream_t s = (hipStream_t)stream;
+    if (desc->mode == 1) {
+        if (desc->t_dst < 4) return HMVAE_ERR_UNSUPPORTED;
+        return hmvae_wgrad_lds_launch(desc, grid.x, s);
+    }
+    if (desc->mode != 0) return HMVAE_ERR_ARG;
     switch (desc->mt) {
         case 1: launch_wgrad<1>(desc, grid, s); break;
         case 2: launch_wgrad<2>(desc, grid, s); break;

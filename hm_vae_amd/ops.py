@@ -27,6 +27,9 @@ WGRAD_PERSISTENT = _os.environ.get("HMVAE_WGRAD_PERSISTENT", "1") != "0"   # let
 # operand fragment from L2 per wave (~20 B/cycle/CU, its real ceiling), and the planes are 1.5x the bytes; the 2.7x
 # shorter MFMA time only pays once the operands are shared through LDS (what comes next).
 WGRAD_BF16X3 = _os.environ.get("HMVAE_WGRAD_BF16X3", "0")
+# Weight-gradient GEMM with operands staged through LDS (hmvae_wgrad_desc.mode = 1): "auto" = timed per layer against
+# the direct kernel, "0" never, "1" wherever the kernel supports the problem.
+WGRAD_LDS = _os.environ.get("HMVAE_WGRAD_LDS", "auto")
 # optional JSON file that persists the autotuner's choices between processes (profiling runs reuse it so the trace
 # holds only the launches of the timed steps)
 TUNE_CACHE = _os.environ.get("HMVAE_TUNE_CACHE")
@@ -486,6 +489,7 @@ class MaskedGemm:
         self._wg_sched = {}
         self._split_tuned = {}
         self._bf_tuned = {}
+        self._mode_tuned = {}
         self._plane_buf = {}
         self._ev_f = self._ev_b = None
         ge = self.geom
@@ -558,6 +562,17 @@ class MaskedGemm:
     def persistent(self, bp):
         return self._split_tuned.get(bp) == "p"
 
+    def lds_eligible(self):
+        ge = self.geom
+        return (not self.wg_transposed) and self.kt >= 2 and ge["t_dst"] >= 4
+
+    def wg_mode(self, bp):
+        if not self.lds_eligible() or self.use_bf(bp):
+            return 0
+        if WGRAD_LDS in ("0", "1"):
+            return int(WGRAD_LDS)
+        return int(self._mode_tuned.get(bp, 0))
+
     def use_bf(self, bp):
         if WGRAD_BF16X3 in ("0", "1"):
             return WGRAD_BF16X3 == "1"
@@ -583,13 +598,17 @@ class MaskedGemm:
     def wg_schedule(self, bp):
         """Persistent weight-gradient launch: (CUs x resident workgroups) workers with equal numbers of reduction chunks
         (planner.build_stream_schedule over the tiles), as device tables."""
-        if bp in self._wg_sched:
-            return self._wg_sched[bp]
+        skey = (bp, self.wg_mode(bp))
+        if skey in self._wg_sched:
+            return self._wg_sched[skey]
         n_tiles = self.n_tiles_t if self.wg_transposed else self.n_tiles
         mt = self.bwd.g.mt if self.wg_transposed else self.wg.mt
         kc = self._k_chunks(bp)
         n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 256
-        per_cu = 2 if mt <= 3 else 1                  # 256 VGPRs at mt 3: two 4-wave workgroups per CU; 320 at mt 4: one
+        # resident workgroups per CU by registers (VGPR + AGPR of the unified 512 per SIMD lane): mt 1 / 2 use 128 / 198,
+        # mt 3 uses 268 and mt 4 333 -> one wave per SIMD (counted with rocprofv3: 838 of 1024 wave slots busy on average
+        # for 1127 one-per-CU workgroups: the fifth round is 40 % empty)
+        per_cu = int(_os.environ.get("HMVAE_WG_PER_CU", "0")) or (2 if (mt <= 2 or self.wg_mode(bp) == 1) else 1)
         n_workers = max(8, (n_cu * per_cu) // 8 * 8)
         segs, wseg, _, _ = P.build_stream_schedule([kc] * n_tiles, [1] * n_tiles, n_workers, min_steps=2)
         items = np.zeros((max(len(segs), 1), 4), dtype=np.int32)
@@ -602,7 +621,7 @@ class MaskedGemm:
             nparts[u] += 1
         sc = dict(items=_dev(items.reshape(-1), self.device), worker_items=_dev(wseg.astype(np.int32).reshape(-1), self.device),
                   n_workers=n_workers, n_parts=len(segs), part0=_dev(part0, self.device), nparts=_dev(nparts, self.device))
-        self._wg_sched[bp] = sc
+        self._wg_sched[skey] = sc
         return sc
 
     def slab_floats(self, bp):
@@ -617,12 +636,13 @@ class MaskedGemm:
     def autotune_split(self, dy, x, dw, bp, slab):
         if bp in self._split_tuned or not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return
-        ck = "wg3_t%d_m%d_k%d_c%d_tr%d_b%d" % (self.n_tiles_t if self.wg_transposed else self.n_tiles, self.wg.mt, self.kt,
+        ck = "wg4_t%d_m%d_k%d_c%d_tr%d_b%d" % (self.n_tiles_t if self.wg_transposed else self.n_tiles, self.wg.mt, self.kt,
                                               self._k_chunks(bp), int(self.wg_transposed), bp)
         hit = _tune_cache_get(ck)
         if hit is not None:
             self._split_tuned[bp] = "p" if hit[0] == "p" else int(hit[0])
             self._bf_tuned[bp] = bool(hit[1]) if len(hit) > 1 else False
+            self._mode_tuned[bp] = int(hit[2]) if len(hit) > 2 else 0
             return
         scratch = torch.empty_like(dw)
         best = None
@@ -630,9 +650,16 @@ class MaskedGemm:
         cands = list(self.split_candidates(bp))
         if WGRAD_PERSISTENT and self._k_chunks(bp) >= 8:
             cands.append("p")
-        modes = [False, True] if WGRAD_BF16X3 == "auto" else [WGRAD_BF16X3 == "1"]
-        for bf in modes:
+        modes = [(False, 0)]
+        if WGRAD_BF16X3 == "auto":
+            modes.append((True, 0))
+        elif WGRAD_BF16X3 == "1":
+            modes = [(True, 0)]
+        if WGRAD_LDS == "auto" and self.lds_eligible() and WGRAD_BF16X3 != "1":
+            modes.append((False, 1))
+        for bf, md in modes:
             self._bf_tuned[bp] = bf
+            self._mode_tuned[bp] = md
             for c in cands:
                 self._split_tuned[bp] = c
 
@@ -642,10 +669,11 @@ class MaskedGemm:
                     _lib.check(_lib.load().hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce")
                 t = self.fwd._time(once)
                 if best is None or t < best[0]:
-                    best = (t, c, bf)
+                    best = (t, c, bf, md)
         self._split_tuned[bp] = best[1]
         self._bf_tuned[bp] = best[2]
-        _tune_cache_put(ck, (best[1], int(best[2])))
+        self._mode_tuned[bp] = best[3]
+        _tune_cache_put(ck, (best[1], int(best[2]), int(best[3])))
 
     def backward_weight(self, dy, x, dw, bp, slab, accumulate=False):
         self.autotune_split(dy, x, dw, bp, slab)
@@ -700,9 +728,9 @@ class MaskedGemm:
 
     def _wg_items(self, bp):
         if not self.persistent(bp):
-            return (None, None, 0, 0)
+            return (None, None, 0, self.wg_mode(bp))
         sc = self.wg_schedule(bp)
-        return (_lib.ptr(sc["items"]), _lib.ptr(sc["worker_items"]), sc["n_workers"], 0)
+        return (_lib.ptr(sc["items"]), _lib.ptr(sc["worker_items"]), sc["n_workers"], self.wg_mode(bp))
 
     def _wg_parts(self, bp):
         if not self.persistent(bp):

@@ -183,7 +183,11 @@ typedef struct {
      * workgroup per (tile, split) as described above. */
     const int32_t* items;
     const int32_t* worker_items;
-    int32_t n_workers, pad_;
+    int32_t n_workers;
+    int32_t mode;            /* 0: operands straight from global memory in MFMA layout.  1: staged through LDS per 4 positions
+                                (gradient rows as whole lines, the activation operand as a window of rows per channel); not
+                                for transposed / bf16-plane / single-tap problems or fewer than 4 positions
+                                (HMVAE_ERR_UNSUPPORTED) */
     /* Optional: both operands as three bf16 planes each (hmvae_split_bf16x3: value = plane0 + plane1 + plane2 exactly),
      * plane p of element i at planes[p * plane_stride + i], same element indexing as dz / x.  When dz_planes is given the
      * products run on the bf16 matrix pipe as six cross terms per fp32 product (everything above 2^-23 of it), fp32

@@ -516,3 +516,43 @@ def test_wgrad_bf16x3_planes_match_fp32_path(dev, monkeypatch):
         outs.append(dw)
     assert float(outs[0].abs().max()) > 0
     assert rel_err(outs[1].cpu().numpy(), outs[0].cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(kt=15, stride=1, pad=7, mode="reflect", t_in=32, B=70),
+    dict(kt=15, stride=2, pad=7, mode="reflect", t_in=64, B=64),
+    dict(kt=15, stride=2, pad=7, mode="zeros", t_in=22, B=130),          # t_out = 11: a partial last stage, zero rows
+    dict(kt=3, stride=1, pad=1, mode="zeros", t_in=6, B=9),
+    dict(kt=31, stride=1, pad=15, mode="reflect", t_in=40, B=8),         # the trajectory model's taps
+])
+def test_wgrad_lds_staged_kernel_matches_direct(dev, monkeypatch, cfg):
+    """hmvae_wgrad_desc.mode = 1 (operands staged through LDS, activation window per channel) against the direct kernel
+    for every split the autotuner may pick, incl. the persistent schedule: same sums, different summation order."""
+    from hm_vae_amd import ops
+    neigh = [[0, 1], [0, 1, 2], [1, 2, 3], [2, 3, 4], [3, 4]]
+    cin, cout = 5 * 6, 5 * 12
+    op = ops.conv_gemm(dev, neigh, cin, cout, cfg["kt"], cfg["stride"], cfg["pad"], cfg["mode"], cfg["t_in"], need_dx=True)
+    assert op.lds_eligible() or op.wg_transposed
+    if op.wg_transposed:
+        pytest.skip("transposed orientation chosen: the LDS kernel does not apply")
+    B = cfg["B"]
+    bp = ops.pad_batch(B)
+    t_out = op.t_out
+    x = torch.zeros(cin * cfg["t_in"], bp, device=dev)
+    dy = torch.zeros(cout * t_out, bp, device=dev)
+    x[:, :B] = torch.randn(cin * cfg["t_in"], B, device=dev)
+    dy[:, :B] = torch.randn(cout * t_out, B, device=dev)
+    slab = torch.empty(op.slab_floats(bp), device=dev)
+    monkeypatch.setattr(ops, "AUTOTUNE", False)
+    ref = None
+    for mode in ("0", "1"):
+        monkeypatch.setattr(ops, "WGRAD_LDS", mode)
+        for split in op.split_candidates(bp) + (["p"] if op._k_chunks(bp) >= 8 else []):
+            op._split_tuned[bp] = split
+            dw = torch.zeros(cout, cin, cfg["kt"], device=dev)
+            op.backward_weight(dy, x, dw, bp, slab)
+            if ref is None:
+                ref = dw
+                assert float(ref.abs().max()) > 0
+            else:
+                assert rel_err(dw.cpu().numpy(), ref.cpu().numpy()) < 2e-6, (mode, split)

@@ -2,7 +2,7 @@
 split), same split; and how far the two results are apart."""
 import sys, os, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-os.environ["HMVAE_WGRAD_BF16X3"] = "auto"
+os.environ["HMVAE_WGRAD_BF16X3"] = "0"; os.environ["HMVAE_WGRAD_LDS"] = "auto"
 from hm_vae_amd import ops, _lib
 from hm_vae_amd.trainer_motion_vae import Trainer
 from hm_vae_amd.utils_common import get_config
@@ -26,10 +26,10 @@ for name, op in zip(names, eng.enc_conv + eng.dec_conv):
     slab = torch.empty(op.slab_floats(bp), device=dev)
     dw = [torch.zeros(cout, cin, kt, device=dev) for _ in range(2)]
     res = []
-    for bf in (False, True):
+    for bf in (False, True):          # second column: the LDS-staged kernel (mode 1), fp32
         best = None
         for c in op.split_candidates(bp) + (["p"] if op._k_chunks(bp) >= 8 else []):
-            op._split_tuned[bp] = c; op._bf_tuned[bp] = bf
+            op._split_tuned[bp] = c; op._bf_tuned[bp] = False; op._mode_tuned[bp] = int(bf)
             def once():
                 op.wgrad_gemm(dy, x, bp, slab)
                 r = op.reduce_desc(slab, dw[int(bf)], bp, False)
@@ -40,10 +40,9 @@ for name, op in zip(names, eng.enc_conv + eng.dec_conv):
         t = timeit(once)
         once(); torch.cuda.synchronize()
         res.append((t, best[1]))
-    tsplit = timeit(lambda: (op._planes("dz", dy), op._planes("x", x)))
     diff = float((dw[0] - dw[1]).abs().max() / dw[0].abs().max())
     useful = 2.0 * op.useful_macs_per_col * bp
-    print("%s mt%d fp32 %.1f us (split %s, %.1f TF) | bf16x3 %.1f us incl. %.1f us operand split (split %s, %.1f TF) | max rel diff %.2e"
-          % (name, op.wg.mt, res[0][0], res[0][1], useful / res[0][0] / 1e6, res[1][0], tsplit, res[1][1], useful / res[1][0] / 1e6, diff))
+    print("%s mt%d direct %.1f us (split %s, %.1f TF) | lds %.1f us (split %s, %.1f TF) | max rel diff %.2e"
+          % (name, op.wg.mt, res[0][0], res[0][1], useful / res[0][0] / 1e6, res[1][0], res[1][1], useful / res[1][0] / 1e6, diff))
     tot[0] += res[0][0]; tot[1] += res[1][0]
-print("sum fp32 %.1f us, bf16x3 %.1f us" % tuple(tot))
+print("sum direct %.1f us, lds %.1f us" % tuple(tot))
