@@ -88,7 +88,7 @@ def instrument_gemms(engine, timer, bp):
             issued = 2.0 * side.g.mfma_cost() * sum(len(l) for l in side.pairs_host)   # what the MFMAs execute
             restore.append((side, "run", timer.wrap(side, "run", fam, lambda *a, _f=useful_f, _i=issued, **k:
                                                     (_f * a[2], _i * a[2]) if len(a) > 2 else (0.0, 0.0))))
-        restore.append((op, "backward_weight", timer.wrap(op, "backward_weight", "wgrad (wgrad_kernel | wreduce_kernel)",
+        restore.append((op, "backward_weight", timer.wrap(op, "backward_weight", "wgrad (wgrad_kernel | wgrad_lds_kernel | wreduce_kernel)",
                                                            lambda *a, _f=useful_f, **k: _f * a[3])))
     return restore
 
@@ -104,19 +104,25 @@ def load_traffic(kernel, batch, phase):
     d = json.load(open(files[-1]))
     # the family label names its kernels: "gather_gemm (a | b)" -> launch-weighted mean over a and b
     names = [n.strip() for n in kernel[kernel.index("(") + 1:kernel.rindex(")")].split("|")] if "(" in kernel else [kernel]
-    # gather family: alternative kernels for the same launch -> launch-weighted mean; wgrad family: GEMM + its reduce are
-    # two parts of one logical launch -> sum
+    # alternative kernels for the same launch -> launch-weighted mean; the weight-gradient family is a GEMM (direct or
+    # LDS-staged kernel) plus its reduce: two parts of one logical launch -> mean over the GEMM kernels + the reduce
     parts = kernel.startswith("wgrad")
     tot = cnt = 0.0
+    extra = 0.0
     for n in names:
         k = d["kernels"].get(n)
-        if k:
-            c = max(k["launches_fetch_pass"], 1)
-            tot += k["traffic_bytes_per_launch"] * (1 if parts else c)
-            cnt += 1 if parts else c
+        if not k:
+            continue
+        if parts and n == "wreduce_kernel":
+            extra += k["traffic_bytes_per_launch"]
+            continue
+        c = max(k["launches_fetch_pass"], 1)
+        tot += k["traffic_bytes_per_launch"] * c
+        cnt += c
     if not cnt:
         return None, None
-    return (tot if parts else tot / cnt), os.path.basename(files[-1])
+    return tot / cnt + extra, os.path.basename(files[-1])
+
 
 
 def fk_microbench(device, iters=20):
