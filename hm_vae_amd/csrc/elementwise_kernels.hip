@@ -359,34 +359,34 @@ extern "C" int hmvae_soa_to_aos(const float* soa, float* aos, int32_t B, int32_t
 }
 
 // ---------------- reparametrize + KL ----------------
-// grid: (bp/256 rounded up, k_edges); thread = one batch column of one edge
+// grid: (bp/256 rounded up, k_edges, d); thread = one batch column of one latent component of one edge.  (One thread
+// walking the d components of its column was a rolled loop of d dependent memory round trips: 12-17 us for a few
+// hundred KB, on the critical path between encoder and decoder.)
 __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* __restrict__ dist, const float* __restrict__ eps,
                                                               float* __restrict__ z, float* __restrict__ kl_partial,
                                                               int k_edges, int dl, int B, int bp, int sample) {
     __shared__ float sh[4];
     const int b = blockIdx.x * 256 + threadIdx.x;
     const int e = blockIdx.y;
+    const int j = blockIdx.z;
     float kl = 0.f;
     if (b < bp) {
         const bool live = b < B;
-        for (int j = 0; j < dl; ++j) {
-            const float mu = dist[(size_t)(e * 2 * dl + j) * bp + b];
-            const float lv = dist[(size_t)(e * 2 * dl + dl + j) * bp + b];
-            float zz = mu;
-            if (sample && live) zz = eps[((size_t)b * k_edges + e) * dl + j] * expf(0.5f * lv) + mu;
-            z[(size_t)(e * dl + j) * bp + b] = live ? zz : 0.f;
-            if (live) kl += 1.f + lv - mu * mu - expf(lv);
-        }
-        kl *= -0.5f;
+        const float mu = dist[(size_t)(e * 2 * dl + j) * bp + b];
+        const float lv = dist[(size_t)(e * 2 * dl + dl + j) * bp + b];
+        float zz = mu;
+        if (sample && live) zz = eps[((size_t)b * k_edges + e) * dl + j] * expf(0.5f * lv) + mu;
+        z[(size_t)(e * dl + j) * bp + b] = live ? zz : 0.f;
+        if (live) kl = -0.5f * (1.f + lv - mu * mu - expf(lv));
     }
     const float tot = block_sum256(kl, sh);
-    if (threadIdx.x == 0) kl_partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    if (threadIdx.x == 0) kl_partial[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tot;
 }
 
 extern "C" int hmvae_reparam_kl_fwd(const float* dist, const float* eps, float* z, float* kl_partial, int32_t k_edges,
                                     int32_t d, int32_t B, int32_t bp, int32_t sample, hmvae_stream_t stream) {
-    if (!dist || !z || !kl_partial || (sample && !eps) || bp < B) return HMVAE_ERR_ARG;
-    dim3 grid((bp + 255) / 256, k_edges);
+    if (!dist || !z || !kl_partial || (sample && !eps) || bp < B || d <= 0 || d > 65535) return HMVAE_ERR_ARG;
+    dim3 grid((bp + 255) / 256, k_edges, d);
     hipLaunchKernelGGL(reparam_kl_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dist, eps, z, kl_partial, k_edges,
                        d, B, bp, sample);
     return LAUNCH_OK();
@@ -398,32 +398,31 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(const float* __rest
                                                               float kl_scale) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     const int e = blockIdx.y;
+    const int j = blockIdx.z;
     if (b >= bp) return;
     const bool live = b < B;
-    for (int j = 0; j < dl; ++j) {
-        const size_t rmu = (size_t)(e * 2 * dl + j) * bp + b;
-        const size_t rlv = (size_t)(e * 2 * dl + dl + j) * bp + b;
-        float gmu = 0.f, glv = 0.f;
-        if (live) {
-            const float mu = dist[rmu], lv = dist[rlv];
-            gmu = kl_scale * mu;
-            glv = kl_scale * 0.5f * (expf(lv) - 1.f);
-            if (use_dz) {
-                const float g = dz[(size_t)(e * dl + j) * bp + b];
-                gmu += g;
-                if (eps) glv += g * eps[((size_t)b * k_edges + e) * dl + j] * 0.5f * expf(0.5f * lv);
-            }
+    const size_t rmu = (size_t)(e * 2 * dl + j) * bp + b;
+    const size_t rlv = (size_t)(e * 2 * dl + dl + j) * bp + b;
+    float gmu = 0.f, glv = 0.f;
+    if (live) {
+        const float mu = dist[rmu], lv = dist[rlv];
+        gmu = kl_scale * mu;
+        glv = kl_scale * 0.5f * (expf(lv) - 1.f);
+        if (use_dz) {
+            const float g = dz[(size_t)(e * dl + j) * bp + b];
+            gmu += g;
+            if (eps) glv += g * eps[((size_t)b * k_edges + e) * dl + j] * 0.5f * expf(0.5f * lv);
         }
-        ddist[rmu] = gmu;
-        ddist[rlv] = glv;
     }
+    ddist[rmu] = gmu;
+    ddist[rlv] = glv;
 }
 
 extern "C" int hmvae_reparam_kl_bwd(const float* dist, const float* eps, const float* dz, float* ddist, int32_t k_edges,
                                     int32_t d, int32_t B, int32_t bp, int32_t use_dz, float kl_scale,
                                     hmvae_stream_t stream) {
-    if (!dist || !ddist || (use_dz && !dz) || bp < B) return HMVAE_ERR_ARG;
-    dim3 grid((bp + 255) / 256, k_edges);
+    if (!dist || !ddist || (use_dz && !dz) || bp < B || d <= 0 || d > 65535) return HMVAE_ERR_ARG;
+    dim3 grid((bp + 255) / 256, k_edges, d);
     hipLaunchKernelGGL(reparam_kl_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dist, eps, dz, ddist, k_edges, d, B,
                        bp, use_dz, kl_scale);
     return LAUNCH_OK();

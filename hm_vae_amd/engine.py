@@ -260,7 +260,7 @@ class VaeEngine(_StepBase):
             k, d = p.edge_num[i + 1], p.lat_dim[i]
             w["ZD%d" % i], w["dZD%d" % i] = buf(k * 2 * d), buf(k * 2 * d)
             w["Z%d" % i], w["dZ%d" % i] = buf(k * d), buf(k * d)
-            w["KLP%d" % i] = torch.zeros(ops.kl_partial_blocks(k, bp), device=dev)
+            w["KLP%d" % i] = torch.zeros(ops.kl_partial_blocks(k, bp, d), device=dev)
         w["H0"], w["dH0"] = buf(p.edge_num[L] * p.dec_feat[0]), buf(p.edge_num[L] * p.dec_feat[0])
         for i in range(L):
             t_conv = p.dec_ts[i + 1]

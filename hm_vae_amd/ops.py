@@ -955,8 +955,9 @@ def reparam_kl_bwd(dist, eps, dz, ddist, k_edges, d, B, bp, use_dz, kl_scale):
                "reparam_kl_bwd")
 
 
-def kl_partial_blocks(k_edges, bp):
-    return k_edges * ((bp + 255) // 256)
+def kl_partial_blocks(k_edges, bp, d):
+    """Entries of the KL partial-sum buffer written by reparam_kl_fwd: one per (latent component, edge, 256 columns)."""
+    return d * k_edges * ((bp + 255) // 256)
 
 
 _PARENTS_C = None

@@ -328,7 +328,8 @@ int hmvae_soa_to_aos(const float* soa, float* aos, int32_t B, int32_t T, int32_t
 
 /* reparametrize + KL: seq_two_hier_sa_vae.py:419-428.
  * dist rows: (e*2d + j) mu, (e*2d + d + j) logvar, [rows][bp]; eps AoS (B*k, d); z rows (e*d + j).
- * kl_partial[block] = sum over the block's columns of -0.5*sum_j(1 + lv - mu^2 - exp(lv))   (b < B only) */
+ * kl_partial[(j * k_edges + e) * ceil(bp/256) + block] = sum over the block's columns of -0.5*(1 + lv - mu^2 - exp(lv))
+ * for component j of edge e (b < B only): d * k_edges * ceil(bp/256) entries */
 int hmvae_reparam_kl_fwd(const float* dist, const float* eps, float* z, float* kl_partial, int32_t k_edges, int32_t d,
                          int32_t B, int32_t bp, int32_t sample, hmvae_stream_t stream);
 /* ddist = dz through z = mu + eps*exp(lv/2) (if use_dz) + kl_scale * dKL/d(mu,lv) */

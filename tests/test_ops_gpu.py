@@ -344,7 +344,7 @@ def test_reparam_kl(dev, B, k_edges, d):
     ((z * gz).sum() + kl_w * kl).backward()
     ds, bp = soa_from_bct(dist.detach().reshape(B, k_edges * 2 * d, 1), dev)
     zs = torch.full((k_edges * d, bp), float("nan"), device=dev)
-    nblk = ops.kl_partial_blocks(k_edges, bp)
+    nblk = ops.kl_partial_blocks(k_edges, bp, d)
     part = torch.full((nblk,), float("nan"), device=dev)
     ops.reparam_kl_fwd(ds, eps.to(dev), zs, part, k_edges, d, B, bp)
     assert rel_err(bct_from_soa(zs, B, k_edges * d, 1).reshape(B * k_edges, d).numpy(), z.detach().numpy()) < 1e-5
