@@ -21,6 +21,8 @@ from . import _lib, ops, topology
 MULTI_REDUCE = _os0.environ.get("HMVAE_MULTI_REDUCE", "0") == "1"
 # 1: targets (transposes + ground-truth FK), noise and the non-encoder weight layouts run on a side stream beside the encoder
 EARLY_SIDE = _os0.environ.get("HMVAE_EARLY_SIDE", "1") != "0"
+# 1: only the first encoder layer's weight layout is packed on the main stream; layers 1.. beside it on the early stream
+PACK_SPLIT = _os0.environ.get("HMVAE_PACK_SPLIT", "1") != "0"
 
 
 class VaePlan:
@@ -220,7 +222,10 @@ class VaeEngine(_StepBase):
         self._pack_stream = None
         self._multipack = None
         self._multipack_late = None
+        self._multipack_mid = None
         self._late_packs = []
+        self._mid_packs = []
+        self._mid_event = None
         self._early = None
         self._multired = None
         import os as _os
@@ -373,6 +378,7 @@ class VaeEngine(_StepBase):
             if self._multipack is None:
                 self._multipack = ops.MultiPack(self.device)
                 self._multipack_late = ops.MultiPack(self.device)
+                self._multipack_mid = ops.MultiPack(self.device)
             # two launches: what the encoder needs right away, and the rest (decoder layouts, every transposed layout),
             # which the early side stream packs while the encoder runs (train_step joins it before the decoder)
             first, late = [], []
@@ -381,8 +387,17 @@ class VaeEngine(_StepBase):
                 (first if (id(op) in enc_ops or not EARLY_SIDE) else late).append((op.fwd, wt))
                 if op.bwd is not None:
                     (late if EARLY_SIDE else first).append((op.bwd, wt))
+            # three launches inside train_step: the first encoder layer's layout now (the pack kernel is a chain of
+            # dependent table reads: ~60 us whatever it packs), the other encoder layouts on the early side stream under
+            # the batch staging and the first convolution (encode() waits for them before layer 1), the rest later
+            mid = []
+            if defer_late and EARLY_SIDE and self.overlap and PACK_SPLIT:
+                keep = id(self.enc_conv[0].fwd)
+                mid = [(sd, wt) for sd, wt in first if id(sd) != keep]
+                first = [(sd, wt) for sd, wt in first if id(sd) == keep]
             self._multipack.run(first)
             self._late_packs = late
+            self._mid_packs = mid
             if not defer_late and late:          # callers outside train_step: everything now, on this stream
                 self._multipack_late.run(late)
                 self._late_packs = []
@@ -427,6 +442,9 @@ class VaeEngine(_StepBase):
         enc_w, enc_b, _ = self.names()
         x = w["X0"]
         for i in range(p.L):
+            if i == 1 and self._mid_event is not None:           # layouts of layers 1.. were packed beside layer 0
+                torch.cuda.current_stream().wait_event(self._mid_event)
+                self._mid_event = None
             if self.enc_conv[i].fused_pool:
                 self.enc_conv[i].forward(x, w["A%d" % i], bp, bias=P[enc_b[i]], flags=_lib.FLAG_LEAKY)
             else:
@@ -469,13 +487,23 @@ class VaeEngine(_StepBase):
         phase2 = iterations >= hp["iteration_interval"]
         sample = hp["kl_w"] != 0
         self._late_packs = []
+        self._mid_packs = []
+        self._mid_event = None
+        # Off the critical path, on the early side stream while the encoder runs: the layouts of encoder layers 1.. (forked
+        # BEFORE the first pack, which only covers layer 0), the targets (transposes + FK of the ground truth,
+        # seq_two_hier_sa_vae.py:343), the noise of every level -- drawn in level order 0..L-1 so the generator is
+        # consumed like the reference (:359-391) -- and the weight layouts the encoder does not read.
+        early = self._early_stream() if (EARLY_SIDE and self.overlap) else None
         if repack:
             self.pack_weights(defer_late=True)
+            if self._mid_packs:
+                with (torch.cuda.stream(early) if early is not None else contextlib.nullcontext()):
+                    self._multipack_mid.run(self._mid_packs)
+                    self._mid_packs = []
+                    if early is not None:
+                        self._mid_event = torch.cuda.Event()
+                        self._mid_event.record(early)
         ops.aos_to_soa(r6, w["X0"], B, T, 144, bp)
-        # Off the critical path, on the early side stream while the encoder runs: the targets (transposes + FK of the
-        # ground truth, seq_two_hier_sa_vae.py:343), the noise of every level -- drawn in level order 0..L-1 so the
-        # generator is consumed like the reference (:359-391) -- and the weight layouts the encoder does not read.
-        early = self._early_stream() if (EARLY_SIDE and self.overlap) else None
         eps = []
         with (torch.cuda.stream(early) if early is not None else contextlib.nullcontext()):
             self.stage_targets(w, rmat)
