@@ -272,11 +272,15 @@ def get_train_loaders_all_data_seq(config, device=None, data_folder=None, n_batc
     B, T = config["batch_size"], config["train_seq_len"]
     if data_folder:
         dev = device or torch.device("cuda")
+        from . import ddp
         ds = DeviceMotionDataset(data_folder, dev)
         fps, rot = bool(config.get("fps_aug_flag", False)), bool(config.get("random_root_rot_flag", False))
-        return (DeviceMotionLoader(ds, B, T, fps, rot, True, 0), DeviceMotionLoader(ds, B, T, fps, rot, False, 1),
-                DeviceMotionLoader(ds, 1, T, fps, rot, True, 2))
+        r = 1000 * ddp.rank()            # every rank draws its own clips (one process per GPU, batch_size sequences each)
+        return (DeviceMotionLoader(ds, B, T, fps, rot, True, r), DeviceMotionLoader(ds, B, T, fps, rot, False, r + 1),
+                DeviceMotionLoader(ds, 1, T, fps, rot, True, r + 2))
     dev = device or (torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"))
     wp = config.get("model_name") == "TrajectoryModel"
-    return (SyntheticMotionLoader(B, T, dev, n_batches, 0, wp), SyntheticMotionLoader(B, T, dev, 8, 10_000, wp),
-            SyntheticMotionLoader(1, T, dev, 4, 20_000, wp))
+    from . import ddp
+    r = 100_000 * ddp.rank()
+    return (SyntheticMotionLoader(B, T, dev, n_batches, r, wp), SyntheticMotionLoader(B, T, dev, 8, r + 10_000, wp),
+            SyntheticMotionLoader(1, T, dev, 4, r + 20_000, wp))
