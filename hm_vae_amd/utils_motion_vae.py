@@ -148,10 +148,10 @@ class DeviceMotionDataset:
         self.n_rows = int(self.seq_len.sum())
         self.device = torch.device(device)
         self.frames = torch.from_numpy(np.concatenate(arrays, axis=0)).to(self.device)
-        mean, std = np.load(__import__("hm_vae_amd.topology", fromlist=["x"]).resolve_asset(
-            "./utils/data/for_all_data_motion_model/all_amass_data_mean_std.npy"))
+        from . import topology
+        mean, std = np.load(topology.resolve_asset("./utils/data/for_all_data_motion_model/all_amass_data_mean_std.npy"))
         std = std.copy()
-        std[std == 0] = 1.0
+        std[std == 0] = 1.0                   # utils_motion_vae.py:100-101
         self.mean = torch.from_numpy(mean.astype(np.float64)).to(self.device)
         self.std = torch.from_numpy(std.astype(np.float64)).to(self.device)
 

@@ -132,7 +132,9 @@ def test_traj_validation_and_test_branch(dev, tag):
     pose = torch.from_numpy(g["in_rot_pos"]).reshape(B, T, 24, 3)
     res = tr.model.sampled_seq_test(pose)
     orc = O.OracleTrajectory(cfg, seeded, g["mean_root"], g["std_root"])
-    ms = np.load(__import__("os").path.join(__import__("helpers").ROOT, "hm_vae_amd", "assets", "all_amass_data_mean_std.npy"))
+    import os
+    import helpers
+    ms = np.load(os.path.join(helpers.ROOT, "hm_vae_amd", "assets", "all_amass_data_mean_std.npy"))
     ms[1, ms[1] == 0] = 1.0
     x = (pose.reshape(B, T, 72) - torch.from_numpy(ms[0, 360:432]).float()) / torch.from_numpy(ms[1, 360:432]).float()
     with torch.no_grad():
