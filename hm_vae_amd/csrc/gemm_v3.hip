@@ -61,7 +61,7 @@ __device__ __forceinline__ void emit(const hmvae_conv3_desc& d, int g, int row, 
     *(f32x4*)dp = s;
 }
 
-template <int NS, int UN>
+template <int NS, int UN, int NA>
 __global__ __launch_bounds__(512, 4) void conv_window_kernel(hmvae_conv3_desc d) {
     constexpr int MAXCH = (V3_MAX_ITEMS + UN - 1) / UN;
     constexpr int MAXI = MAXCH * UN;
@@ -129,7 +129,14 @@ __global__ __launch_bounds__(512, 4) void conv_window_kernel(hmvae_conv3_desc d)
             goff[i] = (unsigned)(d.win_rows[pc * W + j] * d.src_ts) * (unsigned)bp * 4u +
                       (unsigned)(ct * 64 + (rem & 15) * 4) * 4u;
         }
-        const unsigned aslot = (unsigned)(tid < kt * 16 ? tid : tid % (kt * 16)) * 16u;
+        // weight fragments of a 4-channel step: kt * 16 slots of 16 bytes; NA slots per thread (1 up to 32 taps, 2 up to 64:
+        // the folded decoder layers have 61 virtual taps); slots past the end wrap (a second copy of the same bytes)
+        unsigned aslot[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int sl = tid + i * 512;
+            aslot[i] = (unsigned)(sl < kt * 16 ? sl : sl % (kt * 16)) * 16u;
+        }
         const char* __restrict__ wbase = (const char*)(d.wp + woff);
         __syncthreads();
 
@@ -139,19 +146,21 @@ __global__ __launch_bounds__(512, 4) void conv_window_kernel(hmvae_conv3_desc d)
             acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             tot[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        f32x4 rb[NS], ra;
+        f32x4 rb[NS], ra[NA];
         auto gload = [&](int c4) {                   // c4 absolute; the rows table holds steps k0..k1
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const unsigned ro = *(const unsigned*)((const char*)lds_rows + (unsigned)(c4 - k0) * 16u + lrow[i]);
                 rb[i] = *(const f32x4*)(sbase + (ro + goff[i]));
             }
-            ra = *(const f32x4*)(wbase + ((unsigned)(c4 * kt) * 256u + aslot));
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = *(const f32x4*)(wbase + ((unsigned)(c4 * kt) * 256u + aslot[i]));
         };
         auto lstore = [&](char* buf) {
 #pragma unroll
             for (int i = 0; i < NS; ++i) *(f32x4*)(buf + loff[i]) = rb[i];
-            *(f32x4*)(buf + b_bytes + aslot) = ra;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) *(f32x4*)(buf + b_bytes + aslot[i]) = ra[i];
         };
         auto compute = [&](const char* buf) {
             Opnd<UN> r[2];
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(256) void conv3_fixup_kernel(hmvae_conv3_desc d) {
     }
 }
 
-template <int NS, int UN>
+template <int NS, int UN, int NA>
 int launch3(const hmvae_conv3_desc* d, hipStream_t s) {
     const size_t buf = (size_t)4 * d->win * 256 + (size_t)(d->kt + 1) * 256;
     size_t lds = (size_t)4 * V3_MAX_C4 * 4 + 2 * buf;
@@ -297,7 +306,7 @@ int launch3(const hmvae_conv3_desc* d, hipStream_t s) {
     if (red > lds) lds = red;
     if (d->lds_floor > 0 && lds < (size_t)d->lds_floor) lds = (size_t)d->lds_floor;     // pins workgroups per CU
     if (lds > 160 * 1024) return HMVAE_ERR_UNSUPPORTED;
-    auto kern = conv_window_kernel<NS, UN>;
+    auto kern = conv_window_kernel<NS, UN, NA>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return HMVAE_ERR_LAUNCH;
@@ -316,7 +325,7 @@ extern "C" int hmvae_gather_gemm_v3(const hmvae_conv3_desc* d, hmvae_stream_t st
     if (!d || !d->src || !d->dst || !d->wp || !d->items || !d->wave_tab || !d->win_rows || !d->segs || !d->worker_seg ||
         (d->bias && !d->bias_idx))
         return HMVAE_ERR_ARG;
-    if (d->bp <= 0 || (d->bp & 63) || d->n_groups <= 0 || d->n_chunks <= 0 || d->kt <= 0 || d->kt > 32) return HMVAE_ERR_ARG;
+    if (d->bp <= 0 || (d->bp & 63) || d->n_groups <= 0 || d->n_chunks <= 0 || d->kt <= 0 || d->kt > 64) return HMVAE_ERR_ARG;
     if (d->ts != 1 && d->ts != 2 && d->ts != 4 && d->ts != 8) return HMVAE_ERR_ARG;
     if (d->win < 4 || d->win > 32) return HMVAE_ERR_UNSUPPORTED;
     if (d->un < 3 || d->un > 5 || d->max_items <= 0 || d->max_items % d->un) return HMVAE_ERR_ARG;
@@ -325,7 +334,8 @@ extern "C" int hmvae_gather_gemm_v3(const hmvae_conv3_desc* d, hmvae_stream_t st
         return HMVAE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int ns = (64 * d->win + 511) / 512;
-#define V3_CASE(NS_, UN_) case NS_ * 10 + UN_: return launch3<NS_, UN_>(d, s)
+#define V3_CASE(NS_, UN_) \
+    case NS_ * 10 + UN_: return d->kt <= 32 ? launch3<NS_, UN_, 1>(d, s) : launch3<NS_, UN_, 2>(d, s)
     switch (ns * 10 + d->un) {
         V3_CASE(1, 3); V3_CASE(1, 4); V3_CASE(1, 5);
         V3_CASE(2, 3); V3_CASE(2, 4); V3_CASE(2, 5);

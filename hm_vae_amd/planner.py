@@ -351,7 +351,7 @@ def build_window_plan(pairs, kt, chunk, ts, un, n_waves=8, max_items=16, max_win
     n_pos = len(pairs)
     n_chunks = -(-n_pos // chunk)
     q_all = [q for lst in pairs for q, _ in lst]
-    if not q_all or kt > 32:
+    if not q_all or kt > 64:                     # the kernel stages <= 64 taps' weight fragments per channel step
         return None
     q_hi = max(q_all)
     mat = _materialized_windows(pairs, kt, chunk, max_win) if (ts == 1 and kt <= max_items) else None
