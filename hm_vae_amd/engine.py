@@ -494,6 +494,13 @@ class VaeEngine(_StepBase):
         # seq_two_hier_sa_vae.py:343), the noise of every level -- drawn in level order 0..L-1 so the generator is
         # consumed like the reference (:359-391) -- and the weight layouts the encoder does not read.
         early = self._early_stream() if (EARLY_SIDE and self.overlap) else None
+        x0_event = None
+        if early is not None and repack and PACK_SPLIT:
+            # the input transpose runs beside the first pack (both only depend on the previous step)
+            with torch.cuda.stream(early):
+                ops.aos_to_soa(r6, w["X0"], B, T, 144, bp)
+                x0_event = torch.cuda.Event()
+                x0_event.record(early)
         if repack:
             self.pack_weights(defer_late=True)
             if self._mid_packs:
@@ -503,7 +510,10 @@ class VaeEngine(_StepBase):
                     if early is not None:
                         self._mid_event = torch.cuda.Event()
                         self._mid_event.record(early)
-        ops.aos_to_soa(r6, w["X0"], B, T, 144, bp)
+        if x0_event is not None:
+            torch.cuda.current_stream().wait_event(x0_event)
+        else:
+            ops.aos_to_soa(r6, w["X0"], B, T, 144, bp)
         eps = []
         with (torch.cuda.stream(early) if early is not None else contextlib.nullcontext()):
             self.stage_targets(w, rmat)
