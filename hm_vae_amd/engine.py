@@ -78,7 +78,10 @@ class _StepBase:
         self._flat = None
         self._side = None
         self.overlap = _os.environ.get("HMVAE_OVERLAP", "1") != "0"
-        self.n_side = int(_os.environ.get("HMVAE_SIDE_STREAMS", "2"))
+        # One side stream per weight-gradient chain of a step (12-13 forks): measured A/B (shared autotune cache, 100
+        # steps): 2 streams 134.4 k seq/s, 4 / 8 / 12 / 13 / 16 streams 136-138 k, but 3 / 5 / 6 / 7 only 122-134 k -- with
+        # fewer streams than chains the round-robin makes late layers queue behind unrelated early chains.
+        self.n_side = int(_os.environ.get("HMVAE_SIDE_STREAMS", "16"))
         self._turn = 0
         self._pending_red, self._pending_rs = [], []
 
@@ -562,6 +565,7 @@ class VaeEngine(_StepBase):
         hp, p, L = self.hp, self.p, self.p.L
         enc_w, enc_b, dconv = self.names()
         if part in ("all", "dec"):
+            self._turn = 0                      # the same chain -> stream assignment every step
             self._pending_red, self._pending_rs = [], []
             self._backward_decoder(w, phase2, bp, dconv)
             if part == "dec":
