@@ -222,7 +222,6 @@ class VaeEngine(_StepBase):
         # Decoder.forward's API; they are built lazily
         self._init_step_base(device)
         self._ws = {}
-        self._pack_stream = None
         self._multipack = None
         self._multipack_late = None
         self._multipack_mid = None
@@ -231,8 +230,6 @@ class VaeEngine(_StepBase):
         self._mid_event = None
         self._early = None
         self._multired = None
-        import os as _os
-        self.pack_async = _os.environ.get("HMVAE_PACK_ASYNC", "0") == "1"
         self.flops_per_seq = self._count_flops()
 
     # ------------------------------------------------------------------------------------------
@@ -370,52 +367,36 @@ class VaeEngine(_StepBase):
         return lst
 
     def pack_weights(self, side=True, defer_late=False):
-        """Regather the dense weights into MFMA-fragment order (applies the neighbour mask, skeleton.py:96).
-        With `side`, the ~23 small memory-bound pack kernels run on their own stream, forward layouts first in layer
-        order and backward layouts after, each leaving an event its consumer waits on — so they hide under the
-        batch staging and the first convolutions instead of delaying them."""
+        """Regather the dense weights into MFMA-fragment order (applies the neighbour mask, skeleton.py:96): every layout
+        of the model in at most three launches (`side` is kept for callers of the older signature and ignored).  A variant
+        with one launch and one event per layer on its own stream was measured slower (3.33 vs 3.03 ms/step) and removed."""
         lst = self._pack_list()
-        # measured: the per-layer events cost more than the overlap buys at B=256 (3.33 vs 3.03 ms/step), so the
-        # side-stream variant is opt-in
-        if not (side and self.overlap and self.pack_async):
-            if self._multipack is None:
-                self._multipack = ops.MultiPack(self.device)
-                self._multipack_late = ops.MultiPack(self.device)
-                self._multipack_mid = ops.MultiPack(self.device)
-            # two launches: what the encoder needs right away, and the rest (decoder layouts, every transposed layout),
-            # which the early side stream packs while the encoder runs (train_step joins it before the decoder)
-            first, late = [], []
-            enc_ops = set(id(o) for o in self.enc_conv + self.enc_lin)
-            for op, wt in lst:
-                (first if (id(op) in enc_ops or not EARLY_SIDE) else late).append((op.fwd, wt))
-                if op.bwd is not None:
-                    (late if EARLY_SIDE else first).append((op.bwd, wt))
-            # three launches inside train_step: the first encoder layer's layout now (the pack kernel is a chain of
-            # dependent table reads: ~60 us whatever it packs), the other encoder layouts on the early side stream under
-            # the batch staging and the first convolution (encode() waits for them before layer 1), the rest later
-            mid = []
-            if defer_late and EARLY_SIDE and self.overlap and PACK_SPLIT:
-                keep = id(self.enc_conv[0].fwd)
-                mid = [(sd, wt) for sd, wt in first if id(sd) != keep]
-                first = [(sd, wt) for sd, wt in first if id(sd) == keep]
-            self._multipack.run(first)
-            self._late_packs = late
-            self._mid_packs = mid
-            if not defer_late and late:          # callers outside train_step: everything now, on this stream
-                self._multipack_late.run(late)
-                self._late_packs = []
-            return
-        main = torch.cuda.current_stream()
-        if self._pack_stream is None:
-            self._pack_stream = torch.cuda.Stream(device=self.device)
-        ev = torch.cuda.Event()
-        ev.record(main)
-        self._pack_stream.wait_event(ev)
-        with torch.cuda.stream(self._pack_stream):
-            for op, wt in lst:
-                op.pack_side(wt, "f")
-            for op, wt in reversed(lst):
-                op.pack_side(wt, "b")
+        if self._multipack is None:
+            self._multipack = ops.MultiPack(self.device)
+            self._multipack_late = ops.MultiPack(self.device)
+            self._multipack_mid = ops.MultiPack(self.device)
+        # two launches: what the encoder needs right away, and the rest (decoder layouts, every transposed layout),
+        # which the early side stream packs while the encoder runs (train_step joins it before the decoder)
+        first, late = [], []
+        enc_ops = set(id(o) for o in self.enc_conv + self.enc_lin)
+        for op, wt in lst:
+            (first if (id(op) in enc_ops or not EARLY_SIDE) else late).append((op.fwd, wt))
+            if op.bwd is not None:
+                (late if EARLY_SIDE else first).append((op.bwd, wt))
+        # three launches inside train_step: the first encoder layer's layout now (the pack kernel is a chain of
+        # dependent table reads: ~60 us whatever it packs), the other encoder layouts on the early side stream under
+        # the batch staging and the first convolution (encode() waits for them before layer 1), the rest later
+        mid = []
+        if defer_late and EARLY_SIDE and self.overlap and PACK_SPLIT:
+            keep = id(self.enc_conv[0].fwd)
+            mid = [(sd, wt) for sd, wt in first if id(sd) != keep]
+            first = [(sd, wt) for sd, wt in first if id(sd) == keep]
+        self._multipack.run(first)
+        self._late_packs = late
+        self._mid_packs = mid
+        if not defer_late and late:          # callers outside train_step: everything now, on this stream
+            self._multipack_late.run(late)
+            self._late_packs = []
 
     # ------------------------------------------------------------------------------------------
     # forward pieces
@@ -552,8 +533,6 @@ class VaeEngine(_StepBase):
             self._backward(w, phase2, eps, B, bp, part="dec" if stage == "dec" else "all")
             if stage != "dec":
                 self.assign_grads(phase2)
-        if self._pack_stream is not None:
-            torch.cuda.current_stream().wait_stream(self._pack_stream)
         return ls
 
     def backward_rest(self):

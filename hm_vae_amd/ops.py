@@ -491,7 +491,6 @@ class MaskedGemm:
         self._bf_tuned = {}
         self._mode_tuned = {}
         self._plane_buf = {}
-        self._ev_f = self._ev_b = None
         ge = self.geom
         if (self.bwd is not None and not self.folded and ge["stride"] == 1 and ge["pad_mode"] == _lib.PAD_REFLECT
                 and ge["pad"] > 0 and _os.environ.get("HMVAE_WGRAD_T", "1") != "0"):
@@ -509,34 +508,10 @@ class MaskedGemm:
         if self.bwd is not None:
             self.bwd.pack(weight)
 
-    def pack_side(self, weight, which):
-        """Pack one direction on the CURRENT (side) stream and leave an event for the consumer to wait on."""
-        side = self.fwd if which == "f" else self.bwd
-        if side is None:
-            return
-        side.pack(weight)
-        ev = torch.cuda.Event()
-        ev.record()
-        if which == "f":
-            self._ev_f = ev
-        else:
-            self._ev_b = ev
-
-    def _wait(self, which):
-        ev = self._ev_f if which == "f" else self._ev_b
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-            if which == "f":
-                self._ev_f = None
-            else:
-                self._ev_b = None
-
     def forward(self, x, y, bp, bias=None, flags=0, slope=0.2):
-        self._wait("f")
         self.fwd.run(x, y, bp, bias, flags, slope)
 
     def backward_data(self, dy, dx, bp, accumulate=False):
-        self._wait("b")
         self.bwd.run(dy, dx, bp, None, _lib.FLAG_ACCUM if accumulate else 0)
 
     def _k_chunks(self, bp):
