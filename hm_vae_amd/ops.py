@@ -20,7 +20,13 @@ USE_V2 = _os.environ.get("HMVAE_GEMM", "v2") != "v1"
 AUTOTUNE = _os.environ.get("HMVAE_AUTOTUNE", "1") != "0"
 FOLD = _os.environ.get("HMVAE_FOLD", "1") != "0"        # tap folding for convolutions over fewer positions than taps
 USE_V3 = _os.environ.get("HMVAE_V3", "1") != "0"
-WGRAD_PERSISTENT = _os.environ.get("HMVAE_WGRAD_PERSISTENT", "1") != "0"   # let the autotuner consider the persistent launch        # let the autotuner consider the v3 window kernel
+# Let the autotuner consider the persistent (stream-K) weight-gradient launch.  Off by default: timed alone it wins on
+# most layers, but in the step these GEMMs share the chip with the data-gradient chain and with each other, and workers
+# that hold every CU for their whole launch cost the neighbours more than the balanced tail saves.  A/B on the whole step,
+# a fresh autotune per arm, four arms each: 139.2 k seq/s without it (137.6-140.3) vs 136.5 k with it (135.3-138.0); the
+# spread inside an arm is the autotuner picking between near-equal candidates, repeats with one cache agree to 0.2 %.
+# (Timing the candidates as a pair of concurrent launches instead of alone was tried as a proxy and picked worse.)
+WGRAD_PERSISTENT = _os.environ.get("HMVAE_WGRAD_PERSISTENT", "0") != "0"        # let the autotuner consider the v3 window kernel
 # Weight-gradient GEMM on the bf16 matrix pipe through exact three-way bf16 operand planes (hmvae.h, hmvae_wgrad_desc):
 # "0" never (default), "1" always, "auto" lets the autotuner time it against the fp32 MFMA per layer.  Measured on MI355X
 # (tools/wgrad_bf.py, B=256): fp32-grade results (4e-7 from the fp32 MFMA path) but 1.4x SLOWER -- the kernel streams every
