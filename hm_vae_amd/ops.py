@@ -33,26 +33,53 @@ WGRAD_PERSISTENT = _os.environ.get("HMVAE_WGRAD_PERSISTENT", "0") != "0"        
 # operand fragment from L2 per wave (~20 B/cycle/CU, its real ceiling), and the planes are 1.5x the bytes; the 2.7x
 # shorter MFMA time only pays once the operands are shared through LDS (what comes next).
 WGRAD_BF16X3 = _os.environ.get("HMVAE_WGRAD_BF16X3", "0")
-# Weight-gradient GEMM with operands staged through LDS (hmvae_wgrad_desc.mode = 1): "auto" = timed per layer against
-# the direct kernel, "0" never, "1" wherever the kernel supports the problem.
+# Weight-gradient GEMM with operands staged through LDS (hmvae_wgrad_desc.mode = 1): "auto" (default) = timed per layer
+# against the direct kernel, with the staged kernel's time counted at LDS_BIAS of what it measures; "0" never; "1" wherever
+# the kernel supports the problem.  The bias: timed ALONE the direct kernel wins at mt 3 by 5-16 %, but in the step the
+# staged kernel is the better neighbour -- 5.5x fewer L1 accesses and a third fewer bytes through the CU's load path, which
+# is what the data-gradient GEMMs running beside it are bound by (VAE step: 143.2 k seq/s with it everywhere against 136.4 k
+# with the unbiased alone-timed choice; 144-146 k with the in-situ choices of TUNE_DEFAULTS).  Where it loses by more than
+# the bias (the trajectory model's 31-tap layers: 87 vs 95 k seq/s when forced) the direct kernel stays.
 WGRAD_LDS = _os.environ.get("HMVAE_WGRAD_LDS", "auto")
+LDS_BIAS = float(_os.environ.get("HMVAE_LDS_BIAS", "0.83"))
 # optional JSON file that persists the autotuner's choices between processes (profiling runs reuse it so the trace
 # holds only the launches of the timed steps)
 TUNE_CACHE = _os.environ.get("HMVAE_TUNE_CACHE")
+# Read-only defaults shipped with the package: choices made IN the training step (tools/tune_in_situ.py: one knob of one
+# layer at a time, the whole hipGraph step re-captured and timed) for the problems of the shipped configs.  Timed alone,
+# near-equal candidates come out in a different order from run to run, and the order alone does not predict how they
+# behave beside the other streams (the spread between autotune runs was 137.6-140.3 k seq/s).  Keys name the exact
+# problem (shape, batch), so anything else is still timed on first use.  HMVAE_TUNE_DEFAULTS=0 ignores the file.
+TUNE_DEFAULTS = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "assets", "tune_mi355x.json")
+_tune_defaults = None
 _tune_cache = None
+
+
+def _tune_default_get(key):
+    global _tune_defaults
+    if _os.environ.get("HMVAE_TUNE_DEFAULTS", "1") == "0":
+        return None
+    if _tune_defaults is None:
+        import json
+        try:
+            _tune_defaults = json.load(open(TUNE_DEFAULTS))
+        except (OSError, ValueError):
+            _tune_defaults = {}
+    return _tune_defaults.get(key)
 
 
 def _tune_cache_get(key):
     global _tune_cache
     if TUNE_CACHE is None:
-        return None
+        return _tune_default_get(key)
     if _tune_cache is None:
         import json
         try:
             _tune_cache = json.load(open(TUNE_CACHE))
         except (OSError, ValueError):
             _tune_cache = {}
-    return _tune_cache.get(key)
+    hit = _tune_cache.get(key)
+    return hit if hit is not None else _tune_default_get(key)
 
 
 def _tune_cache_put(key, val):
@@ -266,6 +293,22 @@ class _Side:
         torch.cuda.synchronize()
         return sorted(x.elapsed_time(y) for x, y in evs)[1]
 
+    def tune_key(self, bp):
+        g = self.g
+        return "g%d_w%d_p%d_s%d_d%d_m%d_st%s_b%d" % (g.n_groups, g.packed_size, self.n_pos, self.src_ts, self.dst_ts, g.mt,
+                                                      "x".join(map(str, self.strides)), bp)
+
+    def v2_candidates(self, bp):
+        """(column units per wave, K split) pairs the v2 kernel accepts for this problem."""
+        g = self.g
+        out = []
+        for cw in (1, 2, 4):
+            if g.mt * cw > 4 or int(bp) % (64 * cw):
+                continue
+            for ks in ([ks for ks in (2, 4, 8) if float(g.g_nc4.mean()) / ks >= 1.0] or [1]):
+                out.append((cw, ks))
+        return out
+
     def autotune(self, src, dst, bp, bias, flags, slope):
         """Measure, don't guess: time the candidates once per batch size on the real operands (HIP events, scratch
         destination) and keep the fastest: the v2 kernel's (column units per wave, K split), and -- for the temporal
@@ -274,8 +317,7 @@ class _Side:
         if bp in self._tuned or self.tune is not None or not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return
         g = self.g
-        ck = "g%d_w%d_p%d_s%d_d%d_m%d_st%s_b%d" % (g.n_groups, g.packed_size, self.n_pos, self.src_ts, self.dst_ts, g.mt,
-                                                    "x".join(map(str, self.strides)), bp)
+        ck = self.tune_key(bp)
         hit = _tune_cache_get(ck)
         if hit is not None:
             self._tuned[bp] = tuple(hit)
@@ -614,11 +656,14 @@ class MaskedGemm:
         parts_p = n_tiles + 2 * n_cu + 8              # upper bound of the persistent schedule's parts
         return max(max(self.split_candidates(bp)) * per, parts_p * mt * 16 * 64)
 
+    def wg_tune_key(self, bp):
+        return "wg4_t%d_m%d_k%d_c%d_tr%d_b%d" % (self.n_tiles_t if self.wg_transposed else self.n_tiles, self.wg.mt, self.kt,
+                                                 self._k_chunks(bp), int(self.wg_transposed), bp)
+
     def autotune_split(self, dy, x, dw, bp, slab):
         if bp in self._split_tuned or not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return
-        ck = "wg4_t%d_m%d_k%d_c%d_tr%d_b%d" % (self.n_tiles_t if self.wg_transposed else self.n_tiles, self.wg.mt, self.kt,
-                                              self._k_chunks(bp), int(self.wg_transposed), bp)
+        ck = self.wg_tune_key(bp)
         hit = _tune_cache_get(ck)
         if hit is not None:
             self._split_tuned[bp] = "p" if hit[0] == "p" else int(hit[0])
@@ -648,7 +693,7 @@ class MaskedGemm:
                     self.wgrad_gemm(dy, x, bp, slab)             # includes the operand split in bf mode
                     r = self.reduce_desc(slab, scratch, bp, False)
                     _lib.check(_lib.load().hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce")
-                t = self.fwd._time(once)
+                t = self.fwd._time(once) * (LDS_BIAS if md == 1 else 1.0)
                 if best is None or t < best[0]:
                     best = (t, c, bf, md)
         self._split_tuned[bp] = best[1]

@@ -1,0 +1,128 @@
+"""Choose kernel variants IN the training step (GPU box).
+
+    python tools/tune_in_situ.py [--config configs/len64_no_aug_hm_vae.yaml] [--batch 256] [--out hm_vae_amd/assets/tune_mi355x.json]
+
+Start from the autotuner's alone-timed picks, then coordinate descent: one knob of one layer at a time -- the gather
+kernels' (column units, K split), the weight-gradient GEMMs' (split, direct / LDS-staged) -- the whole hipGraph step is
+re-captured and timed, a candidate is kept when it beats the incumbent by more than the measurement noise.  The result
+is written in the autotune-cache format (keys name shape and batch) and merged into the output file.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HMVAE_TUNE_DEFAULTS", "0")        # start from a fresh alone-timed autotune
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default=os.path.join(ROOT, "configs", "len64_no_aug_hm_vae.yaml"))
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--phase", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--passes", type=int, default=2)
+    ap.add_argument("--out", default=os.path.join(ROOT, "hm_vae_amd", "assets", "tune_mi355x.json"))
+    a = ap.parse_args()
+    import bench
+    from hm_vae_amd import ops
+    from hm_vae_amd.trainer_motion_vae import Trainer
+    from hm_vae_amd.utils_common import get_config
+    from hm_vae_amd.graph_step import GraphedStep
+    dev = torch.device("cuda:0")
+    cfg = get_config(a.config)
+    torch.manual_seed(1234)
+    tr = Trainer(cfg)
+    tr.cuda()
+    B, T = a.batch, cfg["train_seq_len"]
+    data = bench.synthetic_device_batch(B, T, seed=0, device=dev)
+    it0 = cfg["iteration_interval"] if a.phase == 2 else 0
+    gs = GraphedStep(tr, cfg, data, it0, use_graph=True)
+    for _ in range(5):
+        gs.run()
+    eng = tr.model.engine()
+    bp = eng.workspace(B)["bp"]
+
+    def measure():
+        gs.graphs = None                       # re-capture with the current choices
+        for _ in range(4):
+            gs.run(lag=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            gs.run(lag=True)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / a.steps * 1e3
+
+    all_ops = eng.enc_conv + eng.dec_conv + [eng.enc_lin[i] for i in (0, eng.p.L - 1)] + [eng.dec_lin[i] for i in (0, eng.p.L - 1)]
+    knobs = []
+    for op in all_ops:
+        for sd in (op.fwd, op.bwd):
+            if sd is not None and bp in sd._tuned:
+                knobs.append(("g", sd))
+        if bp in op._split_tuned:
+            knobs.append(("w", op))
+    base = min(measure(), measure())
+    noise = 0.002 * base
+    print("start: %.4f ms/step (%.0f seq/s), %d knobs" % (base, B / base * 1e3, len(knobs)), flush=True)
+    for ps in range(a.passes):
+        improved = False
+        for kind, obj in knobs:
+            if kind == "g":
+                cur = obj._tuned[bp]
+                if cur[0] == "v3":
+                    continue                   # the window kernel's shapes are left to the alone-timed choice
+                cands = [c for c in obj.v2_candidates(bp) if tuple(c) != tuple(cur[:2])]
+                best_c, best_t = cur, base
+                for c in cands:
+                    obj._tuned[bp] = tuple(c)
+                    obj._tuned_v2[bp] = tuple(c)
+                    t = measure()
+                    if t < best_t - noise:
+                        best_c, best_t = tuple(c), t
+                obj._tuned[bp] = best_c
+                obj._tuned_v2[bp] = tuple(best_c[:2]) if best_c[0] != "v3" else obj._tuned_v2[bp]
+                label = obj.tune_key(bp)
+            else:
+                cur = (obj._split_tuned[bp], obj._mode_tuned.get(bp, 0))
+                modes = [0, 1] if obj.lds_eligible() else [0]
+                cands = [(c, m) for m in modes for c in obj.split_candidates(bp) if (c, m) != cur]
+                best_c, best_t = cur, base
+                for c, m in cands:
+                    obj._split_tuned[bp], obj._mode_tuned[bp] = c, m
+                    t = measure()
+                    if t < best_t - noise:
+                        best_c, best_t = (c, m), t
+                obj._split_tuned[bp], obj._mode_tuned[bp] = best_c
+                label = obj.wg_tune_key(bp)
+            if best_t < base - noise:
+                print("  %-58s %s -> %s   %.4f -> %.4f ms" % (label, cur, best_c, base, best_t), flush=True)
+                base = best_t
+                improved = True
+        base = min(measure(), measure())
+        print("pass %d: %.4f ms/step (%.0f seq/s)" % (ps, base, B / base * 1e3), flush=True)
+        if not improved:
+            break
+    out = {}
+    if os.path.exists(a.out):
+        try:
+            out = json.load(open(a.out))
+        except ValueError:
+            out = {}
+    for kind, obj in knobs:
+        if kind == "g":
+            out[obj.tune_key(bp)] = list(obj._tuned[bp])
+        else:
+            out[obj.wg_tune_key(bp)] = [obj._split_tuned[bp], 0, int(obj._mode_tuned.get(bp, 0))]
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(out, open(a.out, "w"), indent=0, sort_keys=True)
+    print("wrote %d entries to %s" % (len(out), a.out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
