@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--phase", type=int, default=2)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--passes", type=int, default=2)
+    ap.add_argument("--seq-len", type=int, default=0, help="override train_seq_len (trajectory model: config 5 quotes 64)")
     ap.add_argument("--out", default=os.path.join(ROOT, "hm_vae_amd", "assets", "tune_mi355x.json"))
     a = ap.parse_args()
     import bench
@@ -36,16 +37,24 @@ def main():
     from hm_vae_amd.graph_step import GraphedStep
     dev = torch.device("cuda:0")
     cfg = get_config(a.config)
+    if a.seq_len:
+        cfg["train_seq_len"] = a.seq_len
     torch.manual_seed(1234)
     tr = Trainer(cfg)
     tr.cuda()
     B, T = a.batch, cfg["train_seq_len"]
-    data = bench.synthetic_device_batch(B, T, seed=0, device=dev)
-    it0 = cfg["iteration_interval"] if a.phase == 2 else 0
+    is_vae = cfg["model_name"] == "TwoHierSAVAEModel"
+    if is_vae:
+        data = bench.synthetic_device_batch(B, T, seed=0, device=dev)
+        it0 = cfg["iteration_interval"] if a.phase == 2 else 0
+    else:
+        from hm_vae_amd.utils_motion_vae import SyntheticMotionLoader
+        data = next(iter(SyntheticMotionLoader(B, T, dev, 1, 0, with_positions=True)))
+        it0 = 0
     gs = GraphedStep(tr, cfg, data, it0, use_graph=True)
     for _ in range(5):
         gs.run()
-    eng = tr.model.engine()
+    eng = tr.model.engine() if is_vae else tr.model.engine(T)
     bp = eng.workspace(B)["bp"]
 
     def measure():
@@ -59,7 +68,10 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / a.steps * 1e3
 
-    all_ops = eng.enc_conv + eng.dec_conv + [eng.enc_lin[i] for i in (0, eng.p.L - 1)] + [eng.dec_lin[i] for i in (0, eng.p.L - 1)]
+    if is_vae:
+        all_ops = eng.enc_conv + eng.dec_conv + [eng.enc_lin[i] for i in (0, eng.p.L - 1)] + [eng.dec_lin[i] for i in (0, eng.p.L - 1)]
+    else:
+        all_ops = eng.conv + [eng.head]
     knobs = []
     for op in all_ops:
         for sd in (op.fwd, op.bwd):
