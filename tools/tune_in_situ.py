@@ -86,19 +86,31 @@ def main():
         improved = False
         for kind, obj in knobs:
             if kind == "g":
-                cur = obj._tuned[bp]
-                if cur[0] == "v3":
-                    continue                   # the window kernel's shapes are left to the alone-timed choice
-                cands = [c for c in obj.v2_candidates(bp) if tuple(c) != tuple(cur[:2])]
+                cur = tuple(obj._tuned[bp])
+                v2_now = tuple(obj._tuned_v2[bp])
+                cands = [tuple(c) for c in obj.v2_candidates(bp)]
+                if ops.USE_V3 and obj.n_pos >= 4 and obj.g.kt > 1:      # the window kernel where its plan exists
+                    for chunk, ts in ((8, 1), (4, 2)):
+                        if obj.window_plan(chunk, ts) is not None:
+                            cands.append(("v3", chunk, ts) + v2_now)
+                cands = [c for c in cands if c != cur]
                 best_c, best_t = cur, base
                 for c in cands:
-                    obj._tuned[bp] = tuple(c)
-                    obj._tuned_v2[bp] = tuple(c)
-                    t = measure()
+                    obj._tuned[bp] = c
+                    if c[0] != "v3":
+                        obj._tuned_v2[bp] = c
+                    try:
+                        t = measure()
+                    except Exception as e:                           # a shape the kernel refuses: skip
+                        print("    skip", obj.tune_key(bp), c, type(e).__name__, flush=True)
+                        obj._tuned[bp] = cur
+                        obj._tuned_v2[bp] = v2_now
+                        gs.graphs = None
+                        continue
                     if t < best_t - noise:
-                        best_c, best_t = tuple(c), t
+                        best_c, best_t = c, t
                 obj._tuned[bp] = best_c
-                obj._tuned_v2[bp] = tuple(best_c[:2]) if best_c[0] != "v3" else obj._tuned_v2[bp]
+                obj._tuned_v2[bp] = tuple(best_c[3:5]) if best_c[0] == "v3" else tuple(best_c[:2])
                 label = obj.tune_key(bp)
             else:
                 cur = (obj._split_tuned[bp], obj._mode_tuned.get(bp, 0))
