@@ -525,6 +525,28 @@ __device__ __forceinline__ void wreduce_body(const hmvae_wreduce_desc& d, int bl
     const size_t split_stride = (size_t)d.n_tiles * per_tile;
     for (int work = blk; work < d.n_tiles * d.mt; work += nblk) {
         const int tile = work / d.mt, piece = work - tile * d.mt;
+        const float* sl = d.slab + (size_t)tile * per_tile + col;
+        // the slab sums first: their addresses need none of the tables, so these loads are in flight while the row / mask
+        // lookups resolve (behind the `continue` they were one more level of a dependent chain of memory round trips)
+        float sums[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = piece * 16 + r0 + 4 * i;
+            float s0 = 0.f, s1 = 0.f;
+            if (d.tile_part0) {                        // persistent weight-gradient launch: the tile's parts are listed
+                const float* pp = d.slab + (size_t)d.tile_part0[tile] * per_tile + col + row * 64;
+                const int np = d.tile_nparts[tile];
+                for (int sp = 0; sp < np; ++sp) s0 += pp[(size_t)sp * per_tile];
+            } else {
+                int sp = 0;
+                for (; sp + 1 < d.n_split; sp += 2) {
+                    s0 += sl[sp * split_stride + row * 64];
+                    s1 += sl[(sp + 1) * split_stride + row * 64];
+                }
+                if (sp < d.n_split) s0 += sl[sp * split_stride + row * 64];
+            }
+            sums[i] = s0 + s1;
+        }
         const int g = d.tile_g[tile];
         const int gc = d.tile_col0[tile] + col;
         if (gc >= d.g_ncols[g]) continue;
@@ -535,20 +557,12 @@ __device__ __forceinline__ void wreduce_body(const hmvae_wreduce_desc& d, int bl
         const unsigned char* okp = d.pair_ok + d.g_okoff[g] + c;
         const int ok_stride = d.g_nc4[g] * 4;
         float* ocol = d.dense + (size_t)cid * d.chan_stride + tap;
-        const float* sl = d.slab + (size_t)tile * per_tile + col;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = piece * 16 + r0 + 4 * i;
             const int rid = d.row_id[g * rows + row];
             if (rid < 0 || !okp[row * ok_stride]) continue;
-            float s = 0.f;
-            if (d.tile_part0) {                        // persistent weight-gradient launch: the tile's parts are listed
-                const float* pp = d.slab + (size_t)d.tile_part0[tile] * per_tile + col + row * 64;
-                const int np = d.tile_nparts[tile];
-                for (int sp = 0; sp < np; ++sp) s += pp[(size_t)sp * per_tile];
-            } else {
-                for (int sp = 0; sp < d.n_split; ++sp) s += sl[sp * split_stride + row * 64];
-            }
+            float s = sums[i];
             if (d.child_tab == nullptr) {
                 float* o = ocol + (size_t)rid * d.row_stride;
                 if (d.accumulate) s += *o;
