@@ -18,6 +18,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HMVAE_TUNE_DEFAULTS", "0")        # start from a fresh alone-timed autotune
+VERBOSE = os.environ.get("TUNE_VERBOSE", "0") == "1"
 
 
 def main():
@@ -96,6 +97,8 @@ def main():
                 cands = [c for c in cands if c != cur]
                 best_c, best_t = cur, base
                 for c in cands:
+                    if VERBOSE:
+                        print("    try", obj.tune_key(bp), c, flush=True)
                     obj._tuned[bp] = c
                     if c[0] != "v3":
                         obj._tuned_v2[bp] = c
@@ -118,6 +121,8 @@ def main():
                 cands = [(c, m) for m in modes for c in obj.split_candidates(bp) if (c, m) != cur]
                 best_c, best_t = cur, base
                 for c, m in cands:
+                    if VERBOSE:
+                        print("    try", obj.wg_tune_key(bp), (c, m), flush=True)
                     obj._split_tuned[bp], obj._mode_tuned[bp] = c, m
                     t = measure()
                     if t < best_t - noise:
