@@ -116,6 +116,9 @@ _SIGS = {
     "hmvae_fk_bwd": ([_ptr, _i32, _ptr, _i64, C.POINTER(_i32), _i32, _i64, _ptr, _ptr, _ptr, _ptr], _i32),
     "hmvae_decode_tail_loss": ([_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _f32, _f32, _f32, _ptr, _ptr,
                                 C.POINTER(_i32), _ptr], _i32),
+    "hmvae_decode_tail_loss_masked": ([_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _f32, _f32, _f32, _ptr, _ptr,
+                                       C.POINTER(_i32), _ptr], _i32),
+    "hmvae_l2_anchor": ([_ptr, _ptr, C.c_int64, _f32, _f32, _ptr, _ptr, C.POINTER(_i32), _ptr], _i32),
     "hmvae_decode_tail_fwd": ([_ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr, _ptr, _ptr], _i32),
     "hmvae_vae_loss_finalize": ([_ptr, _i32, _ptr, _i32, _ptr, _i32] + [_f32] * 10 + [_ptr, _ptr], _i32),
     "hmvae_finalize_sums": ([_ptr, _i32, _i32, _i32, _f32, _ptr, _ptr], _i32),

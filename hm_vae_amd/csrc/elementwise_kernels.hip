@@ -446,6 +446,36 @@ extern "C" int hmvae_finalize_sums(const float* partial, int32_t n_partial, int3
     return LAUNCH_OK();
 }
 
+// ---------------- test-time optimisation: l2_criterion against an anchor (seq_two_hier_sa_vae.py:1366-1373) ----------------
+// mean((p - p0)^2) over one tensor (p0 NULL: the anchor is zero, the latent regulariser :1366) and its gradient ADDED to g:
+//     g[i] += gscale * (p[i] - p0[i]),   partial[block] = pscale * sum (p - p0)^2 over the block's grid-stride share
+// A fixed grid (L2A_BLOCKS) keeps the partial layout independent of n: several tensors append their blocks to one buffer
+// and one finalize launch sums them in a fixed order.
+constexpr int L2A_BLOCKS = 16;
+__global__ __launch_bounds__(256) void l2_anchor_kernel(const float* __restrict__ p, const float* __restrict__ p0, long long n,
+                                                         float gscale, float pscale, float* __restrict__ g,
+                                                         float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)L2A_BLOCKS * 256) {
+        const float e = p[i] - (p0 ? p0[i] : 0.f);
+        acc += e * e;
+        if (g) g[i] += gscale * e;
+    }
+    const float tot = block_sum256(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot * pscale;
+}
+
+extern "C" int hmvae_l2_anchor(const float* p, const float* p0, int64_t n, float grad_scale, float partial_scale, float* g,
+                               float* partial, int32_t* n_blocks_out, hmvae_stream_t stream) {
+    if (n_blocks_out) *n_blocks_out = L2A_BLOCKS;
+    if (!p && !p0 && !g && !partial) return HMVAE_OK;                        // size query
+    if (!p || !partial || n <= 0) return HMVAE_ERR_ARG;
+    hipLaunchKernelGGL(l2_anchor_kernel, dim3(L2A_BLOCKS), dim3(256), 0, (hipStream_t)stream, p, p0, (long long)n, grad_scale,
+                       partial_scale, g, partial);
+    return LAUNCH_OK();
+}
+
 __global__ __launch_bounds__(256) void vae_loss_finalize_kernel(const float* __restrict__ mse, int n_mse,
                                                                  const float* __restrict__ kl0, int n_kl0,
                                                                  const float* __restrict__ kld, int n_kld, float inv_n6,

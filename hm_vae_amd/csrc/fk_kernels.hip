@@ -552,16 +552,24 @@ extern "C" int hmvae_fk_bwd(const float* rot, int32_t rot_dim, const float* offs
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// MK: every joint's squared errors are weighted by mask[(j*T + t)*bp + b] (l2_masked_criterion, seq_two_hier_sa_vae.py:717-735:
+// the means still divide by the full element counts).
+template <bool MK>
 struct TailLoss {
     const float* x;        // dec_out + t*bp + b
     const float* g6;       // gt 6d, same addressing
     const float* gR;       // gt R rows (j*9+k)
     const float* gP;       // gt pos rows (j*3+k)
+    const float* mk;       // mask rows j (MK only)
     const float* offs;
     float* dx;             // d dec_out
     size_t rs;             // row stride between consecutive channels = T*bp
     float s6, sR, sP;      // sums of squared errors
     float c6, cR, cP;      // 2*weight/numel
+    __device__ __forceinline__ float m(int j) const {
+        if constexpr (MK) return mk[(size_t)j * rs];
+        return 1.f;
+    }
     __device__ __forceinline__ void rot_in(int j, float* in) const {
 #pragma unroll
         for (int k = 0; k < 6; ++k) in[k] = x[(size_t)(j * 6 + k) * rs];
@@ -575,27 +583,38 @@ struct TailLoss {
     __device__ __forceinline__ V3 grad_P(int j, V3 P) {
         const float ex = P.x - gP[(size_t)(j * 3) * rs], ey = P.y - gP[(size_t)(j * 3 + 1) * rs],
                     ez = P.z - gP[(size_t)(j * 3 + 2) * rs];
+        if constexpr (MK) {
+            const float w = m(j), c = cP * w;
+            sP += w * (ex * ex + ey * ey + ez * ez);
+            return {c * ex, c * ey, c * ez};
+        }
         sP += ex * ex + ey * ey + ez * ez;
         return {cP * ex, cP * ey, cP * ez};
     }
     __device__ __forceinline__ void grad_R(int j, const M3& R, M3& dR) {
+        const float w = m(j), c = MK ? cR * w : cR;
+        float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const float e = R.a[k] - gR[(size_t)(j * 9 + k) * rs];
-            sR += e * e;
-            dR.a[k] = cR * e;
+            if constexpr (MK) acc += e * e; else sR += e * e;
+            dR.a[k] = c * e;
         }
+        if constexpr (MK) sR += w * acc;
     }
     __device__ __forceinline__ void emit(int j, const M3& dR) {
         float in[6], din[6];
         rot_in(j, in);
         lift6d_bwd(in, dR, din);
+        const float w = m(j), c = MK ? c6 * w : c6;
+        float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const float e = in[k] - g6[(size_t)(j * 6 + k) * rs];
-            s6 += e * e;
-            dx[(size_t)(j * 6 + k) * rs] = din[k] + c6 * e;
+            if constexpr (MK) acc += e * e; else s6 += e * e;
+            dx[(size_t)(j * 6 + k) * rs] = din[k] + c * e;
         }
+        if constexpr (MK) s6 += w * acc;
     }
 };
 
@@ -617,8 +636,10 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // Every wave recomputes the trunk's forward chain it needs (<= 4 lifts + 3 products); a limb hands its parent
 // S = sum of dP over the subtree and H = H_c R_c^T + S (x) off_c through LDS (12 floats per frame).
 constexpr int TL_FRAMES = 64;
+template <bool MK>
 __global__ __launch_bounds__(256) void decode_tail_loss_kernel(const float* __restrict__ dec, const float* __restrict__ g6,
                                                                const float* __restrict__ gR, const float* __restrict__ gP,
+                                                               const float* __restrict__ mask,
                                                                const float* __restrict__ offs, int T, int B, int bp,
                                                                float c6, float cR, float cP, float* __restrict__ ddec,
                                                                float* __restrict__ partial) {
@@ -632,7 +653,7 @@ __global__ __launch_bounds__(256) void decode_tail_loss_kernel(const float* __re
     const size_t o = (size_t)t * bp + b;
     const bool mine = lane < TL_FRAMES;
     const bool live = mine && b < B;
-    TailLoss io{dec + o, g6 + o, gR + o, gP + o, offs, ddec + o, rs, 0.f, 0.f, 0.f, c6, cR, cP};
+    TailLoss<MK> io{dec + o, g6 + o, gR + o, gP + o, MK ? mask + o : nullptr, offs, ddec + o, rs, 0.f, 0.f, 0.f, c6, cR, cP};
     auto hand_over = [&](int slot, const V3& S, const M3& H) {
         xch[slot][0][lane] = S.x;
         xch[slot][1][lane] = S.y;
@@ -892,18 +913,38 @@ __global__ __launch_bounds__(256) void decode_tail_fwd_kernel(const float* __res
 
 }  // namespace
 
+static int tail_loss_launch(const float* dec_out, const float* gt6d, const float* gtR, const float* gtP, const float* mask,
+                            bool masked, const float* offsets, int32_t T, int32_t B, int32_t bp, float scale_6d,
+                            float scale_rot, float scale_pos, float* d_dec_out, float* partial, int32_t* n_blocks_out,
+                            hmvae_stream_t stream) {
+    if (T <= 0 || T > 65535 || B <= 0 || bp < B || (bp & 63)) return HMVAE_ERR_ARG;
+    dim3 grid(bp / TL_FRAMES, T), block(256);
+    if (n_blocks_out) *n_blocks_out = (int32_t)(grid.x * grid.y);
+    if (!dec_out && !gt6d && !gtR && !gtP && !mask && !d_dec_out && !partial) return HMVAE_OK;      // size query
+    if (!dec_out || !gt6d || !gtR || !gtP || !offsets || !d_dec_out || !partial || (masked && !mask)) return HMVAE_ERR_ARG;
+    if (masked)
+        hipLaunchKernelGGL(decode_tail_loss_kernel<true>, grid, block, 0, (hipStream_t)stream, dec_out, gt6d, gtR, gtP, mask,
+                           offsets, T, B, bp, 2.f * scale_6d, 2.f * scale_rot, 2.f * scale_pos, d_dec_out, partial);
+    else
+        hipLaunchKernelGGL(decode_tail_loss_kernel<false>, grid, block, 0, (hipStream_t)stream, dec_out, gt6d, gtR, gtP, mask,
+                           offsets, T, B, bp, 2.f * scale_6d, 2.f * scale_rot, 2.f * scale_pos, d_dec_out, partial);
+    return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+}
+
 extern "C" int hmvae_decode_tail_loss(const float* dec_out, const float* gt6d, const float* gtR, const float* gtP,
                                       const float* offsets, int32_t T, int32_t B, int32_t bp, float scale_6d,
                                       float scale_rot, float scale_pos, float* d_dec_out, float* partial,
                                       int32_t* n_blocks_out, hmvae_stream_t stream) {
-    if (T <= 0 || T > 65535 || B <= 0 || bp < B || (bp & 63)) return HMVAE_ERR_ARG;
-    dim3 grid(bp / TL_FRAMES, T), block(256);
-    if (n_blocks_out) *n_blocks_out = (int32_t)(grid.x * grid.y);
-    if (!dec_out && !gt6d && !gtR && !gtP && !d_dec_out && !partial) return HMVAE_OK;      // size query
-    if (!dec_out || !gt6d || !gtR || !gtP || !offsets || !d_dec_out || !partial) return HMVAE_ERR_ARG;
-    hipLaunchKernelGGL(decode_tail_loss_kernel, grid, block, 0, (hipStream_t)stream, dec_out, gt6d, gtR, gtP, offsets, T, B,
-                       bp, 2.f * scale_6d, 2.f * scale_rot, 2.f * scale_pos, d_dec_out, partial);
-    return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+    return tail_loss_launch(dec_out, gt6d, gtR, gtP, nullptr, false, offsets, T, B, bp, scale_6d, scale_rot, scale_pos,
+                            d_dec_out, partial, n_blocks_out, stream);
+}
+
+extern "C" int hmvae_decode_tail_loss_masked(const float* dec_out, const float* gt6d, const float* gtR, const float* gtP,
+                                             const float* mask, const float* offsets, int32_t T, int32_t B, int32_t bp,
+                                             float scale_6d, float scale_rot, float scale_pos, float* d_dec_out,
+                                             float* partial, int32_t* n_blocks_out, hmvae_stream_t stream) {
+    return tail_loss_launch(dec_out, gt6d, gtR, gtP, mask, true, offsets, T, B, bp, scale_6d, scale_rot, scale_pos, d_dec_out,
+                            partial, n_blocks_out, stream);
 }
 
 extern "C" int hmvae_decode_tail_fwd(const float* dec_out, const float* offsets, int32_t T, int32_t B, int32_t bp,

@@ -84,6 +84,7 @@ class _StepBase:
         self.n_side = int(_os.environ.get("HMVAE_SIDE_STREAMS", "16"))
         self._turn = 0
         self._pending_red, self._pending_rs = [], []
+        self._skip_wgrad = False          # test-time optimisation of the latents alone: data gradients only
 
     def _scales(self, key, scale):
         k = ("scale", key)
@@ -127,6 +128,8 @@ class _StepBase:
     def _wgrad(self, op, dy, x, name, bp, w, bias=None, before=None):
         """bias: optional (src, grad_name, rows_key, base, n_out, rows_per_out, row_step) for the row-sum kernel.
         before: launches that produce `x`, issued on the same side stream first."""
+        if self._skip_wgrad:
+            return
         slab = w["slabs"][id(op)]
         if not MULTI_REDUCE:
             # default: GEMM + reduction + bias sums all on the side stream, overlapped with the data-gradient chain
@@ -224,6 +227,7 @@ class VaeEngine(_StepBase):
         self._ws = {}
         self._multipack = None
         self._multipack_late = None
+        self._multipack_dec = None
         self._multipack_mid = None
         self._late_packs = []
         self._mid_packs = []
@@ -397,6 +401,20 @@ class VaeEngine(_StepBase):
         if not defer_late and late:          # callers outside train_step: everything now, on this stream
             self._multipack_late.run(late)
             self._late_packs = []
+
+    def pack_decoder(self):
+        """The decoder's layouts only (forward and transposed): what the test-time optimisation loop re-reads."""
+        P, L = self.params, self.p.L
+        _, _, dconv = self.names()
+        if self._multipack_dec is None:
+            self._multipack_dec = ops.MultiPack(self.device)
+        lst = []
+        for op, wt in [(self.dec_lin[i], P["dec.latent_dec_layers.%d.weight" % i]) for i in (0, L - 1)] + \
+                [(self.dec_conv[i], P[dconv[i] + ".weight"]) for i in range(L)]:
+            lst.append((op.fwd, wt))
+            if op.bwd is not None:
+                lst.append((op.bwd, wt))
+        self._multipack_dec.run(lst)
 
     # ------------------------------------------------------------------------------------------
     # forward pieces

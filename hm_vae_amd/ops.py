@@ -1014,11 +1014,37 @@ def decode_tail_loss_blocks(T, B, bp):
     return nb.value
 
 
-def decode_tail_loss(dec, g6, gR, gP, offsets, T, B, bp, s6, sR, sP, ddec, partial):
+def decode_tail_loss(dec, g6, gR, gP, offsets, T, B, bp, s6, sR, sP, ddec, partial, mask=None):
+    """mask: SoA (24*T rows, bp) per-joint weights of l2_masked_criterion (seq_two_hier_sa_vae.py:717-735), or None."""
     nb = C.c_int32(0)
+    if mask is not None:
+        if mask.shape != (24 * T, bp) or not mask.is_contiguous() or mask.dtype != torch.float32:
+            raise ValueError("mask must be a contiguous fp32 (24*T, bp) buffer")
+        _lib.check(_lib.load().hmvae_decode_tail_loss_masked(_lib.ptr(dec), _lib.ptr(g6), _lib.ptr(gR), _lib.ptr(gP),
+                                                             _lib.ptr(mask), _lib.ptr(offsets), T, B, bp, s6, sR, sP,
+                                                             _lib.ptr(ddec), _lib.ptr(partial), C.byref(nb), _lib.stream()),
+                   "decode_tail_loss_masked")
+        return nb.value
     _lib.check(_lib.load().hmvae_decode_tail_loss(_lib.ptr(dec), _lib.ptr(g6), _lib.ptr(gR), _lib.ptr(gP),
                                                   _lib.ptr(offsets), T, B, bp, s6, sR, sP, _lib.ptr(ddec),
                                                   _lib.ptr(partial), C.byref(nb), _lib.stream()), "decode_tail_loss")
+    return nb.value
+
+
+def l2_anchor_blocks():
+    nb = C.c_int32(0)
+    _lib.check(_lib.load().hmvae_l2_anchor(None, None, 0, 0.0, 0.0, None, None, C.byref(nb), None), "l2_anchor")
+    return nb.value
+
+
+def l2_anchor(p, p0, grad_scale, partial_scale, g, partial):
+    """g += grad_scale * (p - p0) (p0 None: zeros; g None: loss only); partial[:blocks] = partial_scale * block sums of (p - p0)^2."""
+    for t in (p, p0, g):
+        if t is not None and (not t.is_contiguous() or t.dtype != torch.float32 or t.numel() != p.numel()):
+            raise ValueError("l2_anchor: contiguous fp32 tensors of one size")
+    nb = C.c_int32(0)
+    _lib.check(_lib.load().hmvae_l2_anchor(_lib.ptr(p), _lib.ptr(p0), p.numel(), grad_scale, partial_scale, _lib.ptr(g),
+                                           _lib.ptr(partial), C.byref(nb), _lib.stream()), "l2_anchor")
     return nb.value
 
 

@@ -1,0 +1,189 @@
+"""Test-time optimisation of latent codes (and then of a copy of the decoder) against partially observed motion.
+
+The inner loop of the reference's interpolation / completion routines (seq_two_hier_sa_vae.py:1270-1541; the loop body is
+:1356-1429, its configuration configs/len_64_test_interpolation.yaml:68-84):
+
+    out = _decode(z_list)                                              # decoder + rot6D lift + FK
+    l   = rec_6d_w * masked_mse(6D) + rec_rot_w * masked_mse(R) + rec_pose_w * masked_mse(pos)     (:717-735, :1363-1365)
+        + reg_w * (mse(z_shallow, 0) + mse(z_deep, 0))                                             (:1366-1367)
+        + reg_w_decoder * sum_p mse(p, p_original)                  [optimize_decoder only]        (:1369-1373)
+    iterations 0..50 step Adam on the latents, later ones Adam (lr * 0.001) on the decoder copy     (:1395-1417)
+
+Here every iteration is a fixed launch sequence on the training step's buffers: latents -> SoA, decoder GEMMs, the masked
+decode-tail loss kernel (forward + FK/lift backward in one launch), the decoder's backward-data chain down to the two
+latents (weight-gradient GEMMs only in the decoder phase), the l2-anchor kernel for the regularisers, one finalize launch,
+HipAdam.  The reference optimises a deep copy of the decoder; this class snapshots the decoder's tensors (the snapshot is also
+the regulariser's anchor) and `restore()` puts them back, so the model is unchanged afterwards.
+
+The released routine cannot run (stale call signatures), so its parity is pinned against the CPU oracle's
+restatement of the same loop only (`OracleVAE.refine_forward`), not against reference outputs: "parity unpinned".
+The trajectory term (`optimize_trajectory`, :1376-1386) is not built.
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .optim import HipAdam
+from .seq_two_hier_sa_vae import get_opt_scheduler
+
+DECODER_PHASE_AFTER = 50           # seq_two_hier_sa_vae.py:1393 `prev_epochs`
+
+
+class LatentRefiner:
+    """One batch of windows.  target_rot_mat (B,T,24,3,3), mask (B,T,24) -- 1 where the frame/joint is observed."""
+
+    def __init__(self, model, hp, target_rot_mat, mask, z_shallow=None, z_deep=None):
+        self.model, self.hp = model, hp
+        self.eng = eng = model.engine()
+        p, dev = eng.p, eng.device
+        if hp.get('optimize_trajectory', False):
+            raise NotImplementedError("optimize_trajectory (seq_two_hier_sa_vae.py:1376-1386) is not built")
+        R = target_rot_mat.to(device=dev, dtype=torch.float32).contiguous()
+        B, T = R.shape[0], R.shape[1]
+        if T != p.T:
+            raise ValueError("window length %d != train_seq_len %d" % (T, p.T))
+        if tuple(mask.shape) != (B, T, 24):
+            raise ValueError("mask must be (B, T, 24)")
+        self.B, self.T = B, T
+        self.w = w = eng.workspace(B)
+        bp = w["bp"]
+        # targets: 6D = the first two columns of R (:1279-1280), R, joint positions by FK (:1282)
+        r6 = torch.stack((R[..., 0], R[..., 1]), dim=-2).reshape(B, T, 144).contiguous()
+        eng.stage_batch(w, r6, R.reshape(B, T, 216))
+        if "MK" not in w:
+            w["MK"] = torch.zeros(24 * T, bp, device=dev)
+            nb = ops.l2_anchor_blocks()
+            w["REGP"] = torch.zeros(2 * nb, device=dev)
+            w["DREGP"] = torch.zeros(max(1, len(self._decoder_names())) * nb, device=dev)
+            w["ZERO1"] = torch.zeros(1, device=dev)
+        ops.aos_to_soa(mask.to(device=dev, dtype=torch.float32).contiguous(), w["MK"], B, T, 24, bp)
+        L = p.L
+        k0, d0, kd, dd = p.edge_num[1], p.lat_dim[0], p.edge_num[L], p.lat_dim[L - 1]
+        if z_shallow is None:                         # :1317-1318: the deep code first, then the shallow one
+            z_deep = torch.randn(B, kd, dd, device=dev)
+            z_shallow = torch.randn(B, k0, d0, device=dev)
+        self.z_shallow = torch.nn.Parameter(z_shallow.to(device=dev, dtype=torch.float32).clone().contiguous())
+        self.z_deep = torch.nn.Parameter(z_deep.to(device=dev, dtype=torch.float32).clone().contiguous())
+        self.z_shallow.grad = torch.zeros_like(self.z_shallow)
+        self.z_deep.grad = torch.zeros_like(self.z_deep)
+        self.gen_opt = HipAdam([self.z_shallow, self.z_deep], lr=hp['opt_lr'], weight_decay=hp['weight_decay'])
+        self.gen_scheduler = get_opt_scheduler(self.gen_opt, hp)
+        self.optimize_decoder = bool(hp.get('optimize_decoder', False))
+        self.anchor = None
+        if self.optimize_decoder:
+            names = self._decoder_names()
+            self.anchor = {n: eng.params[n].detach().clone() for n in names}
+            eng.grad_layout()
+            for n in names:
+                eng.params[n].grad = eng.grad_view(n)
+            self.gen_opt_for_decoder = HipAdam([eng.params[n] for n in names], lr=hp['opt_lr'] * 0.001,
+                                               weight_decay=hp['weight_decay'])
+            self.gen_scheduler_for_decoder = get_opt_scheduler(self.gen_opt_for_decoder, hp)
+        self.it = 0
+        self._packed = False
+        self.losses = torch.zeros(8, device=dev)
+
+    def _decoder_names(self):
+        """The tensors of `dec` the step reads (the two dead middle latent heads receive no gradient in the reference
+        either: their regulariser term is identically zero)."""
+        eng, L = self.eng, self.eng.p.L
+        _, _, dconv = eng.names()
+        names = []
+        for i in range(L):
+            names.append(dconv[i] + ".weight")
+            if eng.p.dec_bias[i]:
+                names.append(dconv[i] + ".bias")
+        for i in (0, L - 1):
+            names += ["dec.latent_dec_layers.%d.weight" % i, "dec.latent_dec_layers.%d.bias" % i]
+        return names
+
+    # ------------------------------------------------------------------------------------------
+    def loss_and_grads(self, decoder_phase):
+        """One forward + backward.  Leaves d l_total / d z in z_*.grad and (decoder_phase) d l_total / d decoder tensors in
+        their gradient views; returns the device tensor [total, reg terms weighted, rec_6d, rec_rot, rec_pose, l_reg,
+        l_reg_decoder, 0]."""
+        eng, w, hp = self.eng, self.w, self.hp
+        p, L, B, T, bp = eng.p, eng.p.L, self.B, self.T, self.w["bp"]
+        if decoder_phase or not self._packed:
+            eng.pack_decoder()
+            self._packed = True
+        eng.load_latents(w, self.z_shallow.data, self.z_deep.data)
+        eng.decode_feats(w)
+        n6, nR, nP = B * T * 144, B * T * 216, B * T * 72
+        ops.decode_tail_loss(w["D%d" % (L - 1)], w["X0"], w["GR"], w["GP"], eng.offsets, T, B, bp, hp["rec_6d_w"] / n6,
+                             hp["rec_rot_w"] / nR, hp["rec_pose_w"] / nP, w["dD%d" % (L - 1)], w["MSEP"], mask=w["MK"])
+        _, _, dconv = eng.names()
+        eng._skip_wgrad = not decoder_phase
+        try:
+            eng._turn = 0
+            eng._backward_decoder(w, True, bp, dconv)
+            eng._join()
+        finally:
+            eng._skip_wgrad = False
+        g0, gd = self.z_shallow.grad, self.z_deep.grad
+        ops.soa_to_aos(w["dZ0"], g0.view(B, -1), B, 1, g0[0].numel(), bp)
+        ops.soa_to_aos(w["dZ%d" % (L - 1)], gd.view(B, -1), B, 1, gd[0].numel(), bp)
+        reg_w = float(hp.get("reg_w", 0.0))
+        nb = ops.l2_anchor_blocks()
+        for k, (z, g) in enumerate(((self.z_shallow, g0), (self.z_deep, gd))):
+            n = z.numel()
+            ops.l2_anchor(z.data, None, 2.0 * reg_w / n, 1.0 / n, g, w["REGP"][k * nb:(k + 1) * nb])
+        reg_dec = float(hp.get("reg_w_decoder", 0.0)) if self.optimize_decoder else 0.0
+        if self.optimize_decoder:
+            for k, name in enumerate(self._decoder_names()):
+                t = eng.params[name]
+                n = t.numel()
+                ops.l2_anchor(t.data, self.anchor[name], 2.0 * reg_dec / n, 1.0 / n,
+                              eng.grad_view(name) if decoder_phase else None, w["DREGP"][k * nb:(k + 1) * nb])
+            dregp, n_dreg = w["DREGP"], w["DREGP"].numel()
+        else:
+            dregp, n_dreg = w["ZERO1"], 1
+        # total = w6 l6 + wR lR + wP lP + reg_w * l_reg + reg_w_decoder * l_reg_decoder  (:1388-1389)
+        ops.vae_loss_finalize(w["MSEP"], w["REGP"], dregp, 1.0 / n6, 1.0 / nR, 1.0 / nP, 1.0, 1.0, hp["rec_6d_w"],
+                              hp["rec_rot_w"], hp["rec_pose_w"], reg_dec, reg_w, self.losses)
+        return self.losses
+
+    def step(self):
+        """One iteration of the loop (:1356-1417).  Returns the loss tensor of the iterate BEFORE the update."""
+        decoder_phase = self.optimize_decoder and self.it > DECODER_PHASE_AFTER
+        ls = self.loss_and_grads(decoder_phase)
+        if decoder_phase:
+            opt, sched = self.gen_opt_for_decoder, self.gen_scheduler_for_decoder
+        else:
+            opt, sched = self.gen_opt, self.gen_scheduler
+        opt.step()
+        if sched is not None:
+            sched.step()
+            opt.sync_lr()
+        self.it += 1
+        return ls
+
+    def run(self, iterations=None):
+        """The whole loop; returns the per-iteration losses as an (iterations, 8) host array (one read-back at the end)."""
+        n = int(self.hp["opt_it"] if iterations is None else iterations)
+        hist = torch.zeros(n, 8, device=self.eng.device)
+        for i in range(n):
+            hist[i].copy_(self.step())
+        return hist.cpu().numpy()
+
+    def decode(self):
+        """The current estimate: (cont6d (B,T,24,6), R (B,T,24,3,3), pos (B,T,24,3))."""
+        with torch.no_grad():
+            self.eng.pack_decoder()
+            return self.eng.decode(self.z_shallow.data, self.z_deep.data, repack=False)
+
+    def restore(self):
+        """Put the original decoder back (the reference optimised a deep copy, :1342)."""
+        if self.anchor is not None:
+            with torch.no_grad():
+                for n, t in self.anchor.items():
+                    self.eng.params[n].copy_(t)
+            self.eng.pack_decoder()
+
+
+def temporal_mask(T, window):
+    """seq_two_hier_sa_vae.py:1300-1304: every `window`-th frame and the last one are observed."""
+    m = np.zeros(T, dtype=np.float32)
+    m[::window] = 1
+    m[-1] = 1
+    return m

@@ -262,6 +262,27 @@ class TwoHierSAVAEModel(nn.Module):
     def gen_seq(self, data, hp, iterations):
         return self.test(data, hp, iterations, hp['max_input_timesteps'])
 
+    def l2_masked_criterion(self, pred, gt, mask):
+        """seq_two_hier_sa_vae.py:717-735 on (B,T,24,...) tensors: (mean of the masked squared error, its (B,T) map).
+        Reporting helper on torch tensors; the optimisation loop itself uses the fused masked decode-tail kernel."""
+        assert pred.size() == gt.size()
+        m = mask.reshape(mask.shape + (1,) * (pred.dim() - 3))
+        loss = (pred - gt) ** 2 * m
+        return loss.mean(), loss.reshape(loss.shape[0], loss.shape[1], -1).mean(dim=-1)
+
+    def refine_window(self, target_rot_mat, mask, hp=None, z_shallow=None, z_deep=None, iterations=None):
+        """The test-time optimisation loop of the interpolation / completion routines (seq_two_hier_sa_vae.py:1356-1429) for
+        a batch of windows: target_rot_mat (B,T,24,3,3), mask (B,T,24).  Returns (cont6d, R, pos, loss history (it, 8));
+        the decoder is restored afterwards, as the reference optimises a deep copy."""
+        from .refine import LatentRefiner
+        ref = LatentRefiner(self, self.hp if hp is None else hp, target_rot_mat, mask, z_shallow, z_deep)
+        try:
+            hist = ref.run(iterations)
+            c6, R, pos = ref.decode()
+        finally:
+            ref.restore()
+        return c6, R, pos, hist
+
     def rot_mat_to_6d(self, rotMatrices):
         """(bs,24,3,3) -> (bs,24,6) = [col0 | col1] (:773-779)"""
         c = torch.stack((rotMatrices[:, :, :, 0], rotMatrices[:, :, :, 1]), dim=-2)

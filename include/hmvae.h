@@ -358,6 +358,18 @@ int hmvae_decode_tail_loss(const float* dec_out, const float* gt6d, const float*
                            const float* offsets, int32_t T, int32_t B, int32_t bp, float scale_6d, float scale_rot,
                            float scale_pos, float* d_dec_out, float* partial, int32_t* n_blocks_out,
                            hmvae_stream_t stream);
+/* The same with l2_masked_criterion (seq_two_hier_sa_vae.py:717-735, the test-time optimisation loops :1363-1365): joint j
+ * of frame (b, t) weighs its squared errors -- 6D, matrix and position alike -- by mask[(j*T + t)*bp + b] (SoA, 24*T
+ * rows); the means keep the full element counts, as `loss.mean()` over the masked product does. */
+int hmvae_decode_tail_loss_masked(const float* dec_out, const float* gt6d, const float* gtR, const float* gtP,
+                                  const float* mask, const float* offsets, int32_t T, int32_t B, int32_t bp,
+                                  float scale_6d, float scale_rot, float scale_pos, float* d_dec_out, float* partial,
+                                  int32_t* n_blocks_out, hmvae_stream_t stream);
+/* l2_criterion of a tensor against an anchor (seq_two_hier_sa_vae.py:1366-1373: the latent regulariser, p0 = NULL = zeros,
+ * and the L2-to-original regulariser of the deep-copied decoder): g[i] += grad_scale * (p[i] - p0[i]) (g may be NULL),
+ * partial[0..*n_blocks_out) = partial_scale * block sums of (p - p0)^2 in a fixed order.  All-NULL: size query. */
+int hmvae_l2_anchor(const float* p, const float* p0, int64_t n, float grad_scale, float partial_scale, float* g,
+                    float* partial, int32_t* n_blocks_out, hmvae_stream_t stream);
 /* decode tail, inference: SoA decoder output -> AoS cont6d (B,T,24,6), R (B,T,24,3,3), pos (B,T,24,3).
  * c6 may be NULL (the frame-major copy of the 6D input is then not written). */
 int hmvae_decode_tail_fwd(const float* dec_out, const float* offsets, int32_t T, int32_t B, int32_t bp, float* c6,

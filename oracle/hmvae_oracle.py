@@ -471,6 +471,44 @@ class OracleVAE:
                     z_dist=zs, dec_out=dec_out, c6=c6, R=R, pos=pos, gt_pos=gt_pos)
 
 
+    # -- test-time optimisation (seq_two_hier_sa_vae.py:1356-1389; masked criterion :717-735) -- SURVEY.md §8 row f-2
+    def refine_forward(self, z_shallow, z_deep, target_rmat, mask, anchor=None, backward=True):
+        """One iteration's losses of the interpolation / completion loop and their gradients.
+
+        z_shallow (B,k1,d0), z_deep (B,kL,d): leaf tensors (requires_grad) or plain tensors; target_rmat (B,T,24,3,3);
+        mask (B,T,24); anchor: name -> original decoder tensor (the `optimize_decoder` regulariser :1369-1373) or None.
+        The released routine does not run (stale `_decode` signature), so nothing pins this restatement but the
+        reference's text: parity unpinned.
+        """
+        hp, p = self.hp, self.plan
+        b, T = target_rmat.shape[0], target_rmat.shape[1]
+        nj = hp["n_joints"]
+        z_list = [z_shallow] + [torch.zeros(b, p.edge_num[i + 1], p.lat_dim[i]) for i in range(1, p.L - 1)] + [z_deep]
+        c6, R, pos, dec_out = self.decode(z_list)
+        gtR = target_rmat.float()
+        g6 = torch.stack((gtR[..., 0], gtR[..., 1]), dim=-2).reshape(b, T, nj, 6)          # :1279-1280
+        gt_pos = fk_positions(gtR.reshape(b * T, nj, 3, 3), self.parents, self.offsets).reshape(b, T, nj, 3)
+
+        def masked(pred, gt):                                                               # :717-735
+            m = mask.float().reshape(tuple(mask.shape) + (1,) * (pred.dim() - 3))
+            return (((pred - gt) ** 2) * m).mean()
+
+        l6, lr, lp = masked(c6, g6), masked(R, gtR), masked(pos, gt_pos)
+        l_reg = (z_shallow ** 2).mean() + (z_deep ** 2).mean()                              # :1366-1367
+        l_reg_dec = torch.zeros(())
+        if anchor is not None:
+            for n, t0 in anchor.items():
+                l_reg_dec = l_reg_dec + ((self.params[n] - t0) ** 2).mean()
+        reg_dec_w = hp.get("reg_w_decoder", 0.0) if anchor is not None else 0.0
+        total = hp["rec_6d_w"] * l6 + hp["rec_rot_w"] * lr + hp["rec_pose_w"] * lp + hp.get("reg_w", 0.0) * l_reg + \
+            reg_dec_w * l_reg_dec
+        if backward:
+            for t in list(self.params.values()) + [z_shallow, z_deep]:
+                t.grad = None
+            total.backward()
+        return dict(total=total, rec_6d=l6, rec_rot=lr, rec_pose=lp, reg=l_reg, reg_decoder=l_reg_dec, c6=c6, R=R, pos=pos)
+
+
 # --------------------------------------------------------------------------------------
 # TrajectoryModel (trajectory_pred_model.py:45-115, 176-265, 283-305) — SURVEY.md §8 row f-1
 # --------------------------------------------------------------------------------------
