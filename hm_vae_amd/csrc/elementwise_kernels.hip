@@ -450,8 +450,9 @@ extern "C" int hmvae_finalize_sums(const float* partial, int32_t n_partial, int3
 // mean((p - p0)^2) over one tensor (p0 NULL: the anchor is zero, the latent regulariser :1366) and its gradient ADDED to g:
 //     g[i] += gscale * (p[i] - p0[i]),   partial[block] = pscale * sum (p - p0)^2 over the block's grid-stride share
 // A fixed grid (L2A_BLOCKS) keeps the partial layout independent of n: several tensors append their blocks to one buffer
-// and one finalize launch sums them in a fixed order.
-constexpr int L2A_BLOCKS = 16;
+// and one finalize launch sums them in a fixed order.  (16 blocks took 73 us on the decoder's 1.8 M-float tensors and were
+// half of an iteration's GPU time; 128 blocks stream them at HBM/L2 speed.)
+constexpr int L2A_BLOCKS = 128;
 __global__ __launch_bounds__(256) void l2_anchor_kernel(const float* __restrict__ p, const float* __restrict__ p0, long long n,
                                                          float gscale, float pscale, float* __restrict__ g,
                                                          float* __restrict__ partial) {

@@ -19,6 +19,8 @@ The released routine cannot run (stale call signatures), so its p
 restatement of the same loop only (`OracleVAE.refine_forward`), not against reference outputs: "parity unpinned".
 The trajectory term (`optimize_trajectory`, :1376-1386) is not built.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -32,8 +34,13 @@ DECODER_PHASE_AFTER = 50           # seq_two_hier_sa_vae.py:1393 `prev_epochs`
 class LatentRefiner:
     """One batch of windows.  target_rot_mat (B,T,24,3,3), mask (B,T,24) -- 1 where the frame/joint is observed."""
 
-    def __init__(self, model, hp, target_rot_mat, mask, z_shallow=None, z_deep=None):
+    def __init__(self, model, hp, target_rot_mat, mask, z_shallow=None, z_deep=None, use_graph=None):
         self.model, self.hp = model, hp
+        # an iteration is ~35 (latent phase) / ~75 (decoder phase) launches of a few microseconds each at the reference's
+        # batch of one window: replayed from a hipGraph per phase (the phase's first iteration runs eagerly -- it creates
+        # the optimiser's tables -- the second is captured)
+        self.use_graph = (os.environ.get("HMVAE_REFINE_GRAPH", "1") != "0") if use_graph is None else bool(use_graph)
+        self._graphs, self._eager_done = {}, {False: 0, True: 0}
         self.eng = eng = model.engine()
         p, dev = eng.p, eng.device
         if hp.get('optimize_trajectory', False):
@@ -81,6 +88,9 @@ class LatentRefiner:
             self.gen_scheduler_for_decoder = get_opt_scheduler(self.gen_opt_for_decoder, hp)
         self.it = 0
         self._packed = False
+        self._decoder_moved = False
+        if "DREGP" in w:
+            w["DREGP"].zero_()
         self.losses = torch.zeros(8, device=dev)
 
     def _decoder_names(self):
@@ -129,34 +139,55 @@ class LatentRefiner:
             n = z.numel()
             ops.l2_anchor(z.data, None, 2.0 * reg_w / n, 1.0 / n, g, w["REGP"][k * nb:(k + 1) * nb])
         reg_dec = float(hp.get("reg_w_decoder", 0.0)) if self.optimize_decoder else 0.0
-        if self.optimize_decoder:
+        if self.optimize_decoder and (decoder_phase or self._decoder_moved):
+            # (before the first decoder update every term is exactly zero -- p == p_original -- and DREGP still holds zeros)
             for k, name in enumerate(self._decoder_names()):
                 t = eng.params[name]
                 n = t.numel()
                 ops.l2_anchor(t.data, self.anchor[name], 2.0 * reg_dec / n, 1.0 / n,
                               eng.grad_view(name) if decoder_phase else None, w["DREGP"][k * nb:(k + 1) * nb])
-            dregp, n_dreg = w["DREGP"], w["DREGP"].numel()
-        else:
-            dregp, n_dreg = w["ZERO1"], 1
+            self._decoder_moved = True
+        dregp = w["DREGP"] if self.optimize_decoder else w["ZERO1"]
         # total = w6 l6 + wR lR + wP lP + reg_w * l_reg + reg_w_decoder * l_reg_decoder  (:1388-1389)
         ops.vae_loss_finalize(w["MSEP"], w["REGP"], dregp, 1.0 / n6, 1.0 / nR, 1.0 / nP, 1.0, 1.0, hp["rec_6d_w"],
                               hp["rec_rot_w"], hp["rec_pose_w"], reg_dec, reg_w, self.losses)
         return self.losses
 
+    def _graph_for(self, decoder_phase, opt):
+        g = self._graphs.get(decoder_phase)
+        if g is not None or not self.use_graph or self._eager_done[decoder_phase] < 1:
+            return g
+        torch.cuda.synchronize()
+        host_before = dict(opt._host_step)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.loss_and_grads(decoder_phase)
+            opt.step()
+        opt._host_step = host_before          # capture records the counter increments without executing them
+        opt.resync_device_steps()
+        self._graphs[decoder_phase] = g
+        return g
+
     def step(self):
         """One iteration of the loop (:1356-1417).  Returns the loss tensor of the iterate BEFORE the update."""
         decoder_phase = self.optimize_decoder and self.it > DECODER_PHASE_AFTER
-        ls = self.loss_and_grads(decoder_phase)
         if decoder_phase:
             opt, sched = self.gen_opt_for_decoder, self.gen_scheduler_for_decoder
         else:
             opt, sched = self.gen_opt, self.gen_scheduler
-        opt.step()
+        g = self._graph_for(decoder_phase, opt)
+        if g is None:
+            self.loss_and_grads(decoder_phase)
+            opt.step()
+            self._eager_done[decoder_phase] += 1
+        else:
+            g.replay()
+            opt.advance_host_steps(1)
         if sched is not None:
             sched.step()
             opt.sync_lr()
         self.it += 1
-        return ls
+        return self.losses
 
     def run(self, iterations=None):
         """The whole loop; returns the per-iteration losses as an (iterations, 8) host array (one read-back at the end)."""

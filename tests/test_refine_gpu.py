@@ -138,6 +138,7 @@ def test_one_iteration_matches_oracle(dev, decoder_phase):
     anchor_cpu = {n: (seeded[n] + 0.01 * torch.randn(seeded[n].shape, generator=gen)) for n in names}
     for n in names:
         ref.anchor[n].copy_(anchor_cpu[n].to(dev))
+    ref._decoder_moved = True                 # (the loop skips the identically-zero term until the decoder's first update)
     ls = ref.loss_and_grads(decoder_phase).cpu().numpy()
 
     orc = O.OracleVAE(cfg, seeded, offsets=offsets())
@@ -219,3 +220,26 @@ def test_full_loop_interpolates_and_restores(dev):
             assert torch.equal(t.detach().cpu(), seeded[n]), n
     l, per_frame = model.l2_masked_criterion(R, target.to(dev), mask.to(dev))
     assert per_frame.shape == (B, T) and float(l) >= 0
+
+
+def test_graph_replay_equals_eager(dev, monkeypatch):
+    """The per-phase hipGraph replay runs the same launches as the eager loop: same loss history, same result."""
+    from hm_vae_amd import refine
+    monkeypatch.setattr(refine, "DECODER_PHASE_AFTER", 3)
+    cfg = interp_cfg()
+    model, plan, seeded = make_model(cfg, dev)
+    B, T = 1, cfg["train_seq_len"]                    # the reference's batch: one window
+    target, mask = smooth_rotations(B, T, 31), joint_mask(B, T, cfg["interpolation_window"], 32)
+    g = torch.Generator().manual_seed(33)
+    z0 = torch.randn(B, plan.edge_num[1], plan.lat_dim[0], generator=g)
+    zd = torch.randn(B, plan.edge_num[plan.L], plan.lat_dim[plan.L - 1], generator=g)
+    out = []
+    for use_graph in (False, True):
+        ref = refine.LatentRefiner(model, cfg, target, mask, z0, zd, use_graph=use_graph)
+        hist = ref.run(9)
+        c6, R, pos = ref.decode()
+        ref.restore()
+        assert (len(ref._graphs) == 2) == use_graph
+        out.append((hist, pos.cpu().numpy()))
+    assert rel_err(out[1][0][:, 0], out[0][0][:, 0]) < 1e-5
+    assert rel_err(out[1][1], out[0][1]) < 1e-5
