@@ -84,6 +84,7 @@ class _StepBase:
         self.n_side = int(_os.environ.get("HMVAE_SIDE_STREAMS", "16"))
         self._turn = 0
         self._pending_red, self._pending_rs = [], []
+        self._events = {}
         self._skip_wgrad = False          # test-time optimisation of the latents alone: data gradients only
 
     def _scales(self, key, scale):
@@ -107,6 +108,20 @@ class _StepBase:
     # They only READ dY and the forward activations and write gradient slices nobody else touches, so they overlap
     # with the backward-data chain of the following layers (two kernels that each leave SIMDs idle in their tails
     # fill the chip together).  Fork = event on the main stream once dY is final; join = end of _backward.
+    # Every cross-stream dependency goes through an event this object owns for its lifetime (no event is created or
+    # destroyed inside a step or a stream capture: ~40 event objects per step less for the host to make and drop).
+    def _event(self, key):
+        ev = self._events.get(key)
+        if ev is None:
+            ev = self._events[key] = torch.cuda.Event()
+        return ev
+
+    def _stream_wait(self, waiter, waited, key):
+        """`waiter` waits for everything queued on `waited` so far."""
+        ev = self._event(key)
+        ev.record(waited)
+        waiter.wait_event(ev)
+
     def _fork(self):
         if not self.overlap:
             return None
@@ -115,15 +130,14 @@ class _StepBase:
             self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.n_side)]
         self._turn = (self._turn + 1) % self.n_side
         side = self._side[self._turn]
-        ev = torch.cuda.Event()
-        ev.record(main)
-        side.wait_event(ev)
+        self._stream_wait(side, main, ("fork", self._turn))
         return torch.cuda.stream(side)
 
     def _join(self):
         if self.overlap and self._side is not None:
-            for s in self._side:
-                torch.cuda.current_stream().wait_stream(s)
+            main = torch.cuda.current_stream()
+            for i, s in enumerate(self._side):
+                self._stream_wait(main, s, ("join", i))
 
     def _wgrad(self, op, dy, x, name, bp, w, bias=None, before=None):
         """bias: optional (src, grad_name, rows_key, base, n_out, rows_per_out, row_step) for the row-sum kernel.
@@ -423,7 +437,7 @@ class VaeEngine(_StepBase):
         main = torch.cuda.current_stream()
         if self._early is None:
             self._early = torch.cuda.Stream(device=self.device)
-        self._early.wait_stream(main)
+        self._stream_wait(self._early, main, "early_fork")
         return self._early
 
     def stage_batch(self, w, r6, rmat):
@@ -501,7 +515,7 @@ class VaeEngine(_StepBase):
             # the input transpose runs beside the first pack (both only depend on the previous step)
             with torch.cuda.stream(early):
                 ops.aos_to_soa(r6, w["X0"], B, T, 144, bp)
-                x0_event = torch.cuda.Event()
+                x0_event = self._event("x0")
                 x0_event.record(early)
         if repack:
             self.pack_weights(defer_late=True)
@@ -510,7 +524,7 @@ class VaeEngine(_StepBase):
                     self._multipack_mid.run(self._mid_packs)
                     self._mid_packs = []
                     if early is not None:
-                        self._mid_event = torch.cuda.Event()
+                        self._mid_event = self._event("mid")
                         self._mid_event.record(early)
         if x0_event is not None:
             torch.cuda.current_stream().wait_event(x0_event)
@@ -532,7 +546,7 @@ class VaeEngine(_StepBase):
                 self._multipack_late.run(self._late_packs)
         self.encode(w, (0, L - 1))
         if early is not None:
-            torch.cuda.current_stream().wait_stream(early)
+            self._stream_wait(torch.cuda.current_stream(), early, "early_join")
         for i in (0, L - 1):
             k, d = p.edge_num[i + 1], p.lat_dim[i]
             ops.reparam_kl_fwd(w["ZD%d" % i], eps[i], w["Z%d" % i], w["KLP%d" % i], k, d, B, bp, sample)

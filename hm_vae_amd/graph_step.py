@@ -8,6 +8,25 @@ import torch
 
 from . import ddp
 
+# Captured graphs are never destroyed.  Destroying a hipGraph that was captured across the engine's side streams and then
+# running eager multi-stream work corrupts the host heap inside the HIP runtime of this ROCm release: glibc aborts in
+# hipDeviceSynchronize ("corrupted size vs. prev_size"; "free(): invalid pointer" under MALLOC_CHECK_=3).  Found with
+# tools/tune_in_situ.py (re-captures the step per candidate): reproducible within 3 re-captures on the TrajectoryModel, gone
+# with HMVAE_OVERLAP=0 (single stream) and gone when the old graphs are kept alive; persistent instead of temporary events
+# did not change it.  A training run re-captures once (phase switch), a refinement loop captures two graphs per window
+# batch: they are parked here (host memory: a few hundred KB each).
+_RETIRED = []
+MAX_RETIRED = 256
+
+
+def retire(*graphs):
+    _RETIRED.extend(g for g in graphs if g is not None)
+
+
+def may_capture():
+    """False once MAX_RETIRED graphs are parked: callers that create graphs per work item fall back to eager launches."""
+    return len(_RETIRED) < MAX_RETIRED
+
 
 class GraphedStep:
     def __init__(self, trainer, cfg, data, iterations, use_graph=True, warmup=3):
@@ -100,6 +119,9 @@ class GraphedStep:
                 self.tr.gen_opt.advance_host_steps(0)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        if self.graphs is not None:
+            retire(*self.graphs)
+        retire(self.g1b)
         g1 = torch.cuda.CUDAGraph()
         g2 = None
         self.g1b = None
@@ -129,6 +151,14 @@ class GraphedStep:
             self.tr.gen_opt._host_step = host_before
             self.tr.gen_opt.resync_device_steps()
         self.graphs = (g1, g2)
+
+    def __del__(self):
+        try:
+            if self.graphs is not None:
+                retire(*self.graphs)
+            retire(self.g1b)
+        except Exception:
+            pass
 
     def run(self, lag=False):
         """One training step; returns the nine loss floats like Trainer.gen_update.

@@ -24,7 +24,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _lib, graph_step, ops
 from .optim import HipAdam
 from .seq_two_hier_sa_vae import get_opt_scheduler
 
@@ -155,7 +155,7 @@ class LatentRefiner:
 
     def _graph_for(self, decoder_phase, opt):
         g = self._graphs.get(decoder_phase)
-        if g is not None or not self.use_graph or self._eager_done[decoder_phase] < 1:
+        if g is not None or not self.use_graph or self._eager_done[decoder_phase] < 1 or not graph_step.may_capture():
             return g
         torch.cuda.synchronize()
         host_before = dict(opt._host_step)
@@ -203,6 +203,12 @@ class LatentRefiner:
             self.eng.pack_decoder()
             return self.eng.decode(self.z_shallow.data, self.z_deep.data, repack=False)
 
+    def __del__(self):
+        try:
+            graph_step.retire(*self._graphs.values())
+        except Exception:
+            pass
+
     def restore(self):
         """Put the original decoder back (the reference optimised a deep copy, :1342)."""
         if self.anchor is not None:
@@ -210,6 +216,8 @@ class LatentRefiner:
                 for n, t in self.anchor.items():
                     self.eng.params[n].copy_(t)
             self.eng.pack_decoder()
+        graph_step.retire(*self._graphs.values())       # parked, not destroyed (graph_step.py)
+        self._graphs = {}
 
 
 def temporal_mask(T, window):

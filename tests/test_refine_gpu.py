@@ -238,8 +238,8 @@ def test_graph_replay_equals_eager(dev, monkeypatch):
         ref = refine.LatentRefiner(model, cfg, target, mask, z0, zd, use_graph=use_graph)
         hist = ref.run(9)
         c6, R, pos = ref.decode()
-        ref.restore()
         assert (len(ref._graphs) == 2) == use_graph
+        ref.restore()
         out.append((hist, pos.cpu().numpy()))
     assert rel_err(out[1][0][:, 0], out[0][0][:, 0]) < 1e-5
     assert rel_err(out[1][1], out[0][1]) < 1e-5

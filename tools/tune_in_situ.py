@@ -35,7 +35,7 @@ def main():
     from hm_vae_amd import ops
     from hm_vae_amd.trainer_motion_vae import Trainer
     from hm_vae_amd.utils_common import get_config
-    from hm_vae_amd.graph_step import GraphedStep
+    from hm_vae_amd.graph_step import GraphedStep, retire
     dev = torch.device("cuda:0")
     cfg = get_config(a.config)
     if a.seq_len:
@@ -59,6 +59,9 @@ def main():
     bp = eng.workspace(B)["bp"]
 
     def measure():
+        if gs.graphs is not None:              # never destroyed: see graph_step.retire
+            retire(*gs.graphs)
+            retire(gs.g1b)
         gs.graphs = None                       # re-capture with the current choices
         for _ in range(4):
             gs.run(lag=True)
