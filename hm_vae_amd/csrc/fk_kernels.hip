@@ -845,7 +845,11 @@ __global__ __launch_bounds__(256) void decode_tail_fwd_kernel(const float* __res
             for (int i = 0; i < LIFTS; ++i) {
                 const int j = j0 + i * (256 / TF_FRAMES);
 #pragma unroll
-                for (int k = 0; k < 6; ++k) in[g][i][k] = x[(size_t)(j * 6 + k) * rs];
+                // nontemporal: the decoder output is read exactly once (measured on one box, interleaved builds: 96-103 us
+                // against 104.4-104.8 us with plain loads at 262 144 frames; nontemporal STORES of R / positions made it
+                // 116 us together with these loads and 100 / 144 us (without / with the 6D copy) alone; nontemporal
+                // loads in the frame-major FK kernels cost 2-5 %)
+                for (int k = 0; k < 6; ++k) in[g][i][k] = __builtin_nontemporal_load(&x[(size_t)(j * 6 + k) * rs]);
             }
         }
     }
