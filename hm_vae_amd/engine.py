@@ -206,6 +206,7 @@ class VaeEngine(_StepBase):
         # ---- decoder ops ----
         self.dec_conv, self.dec_unpool, self.dec_lin = [], [], {}
         self.cD = p.dec_cout[L - 2] // p.edge_num[1]          # running channels per edge before the concat
+        self.enc_cut = L // 2                                 # encoder layers >= enc_cut: the coarse half (grad bucket / backward cut)
         self.cH = p.ch_base[1]                                # skip (hier_feats[L-1]) channels per edge
         assert p.dec_cin[L - 1] // p.edge_num[0] == self.cD + self.cH
         for i in range(L):
@@ -337,9 +338,15 @@ class VaeEngine(_StepBase):
         for i in (0, L - 1):
             always += ["dec.latent_dec_layers.%d.%s" % (i, s) for s in ("weight", "bias")]
         n_dec_names = len(always)
-        for i in range(L):
+        # then the encoder's coarse half (layers L-1 .. L/2 and the deep latent head): most of the encoder's bytes, final
+        # after the first, cheap part of its backward -- a second asynchronous all-reduce beside the fine layers' backward;
+        # the fine layers (large T, small weights) come last and are the only exposed collective
+        for i in range(L - 1, self.enc_cut - 1, -1):
             always += [enc_w[i], enc_b[i]]
         always += ["enc.latent_enc_layers.%d.%s" % (L - 1, s) for s in ("weight", "bias")]
+        n_hi_names = len(always)
+        for i in range(self.enc_cut - 1, -1, -1):
+            always += [enc_w[i], enc_b[i]]
         phase2 = ["enc.latent_enc_layers.0.%s" % s for s in ("weight", "bias")]
         never = []
         for i in range(1, L - 1):
@@ -354,6 +361,7 @@ class VaeEngine(_StepBase):
         n1 = offs[phase2[0]]
         n2 = offs[never[0]] if never else o
         self.n_dec_floats = offs[always[n_dec_names]]          # [0, n_dec_floats): every decoder gradient
+        self.n_hi_floats = offs[always[n_hi_names]] if n_hi_names < len(always) else n1   # [n_dec, n_hi): coarse encoder half
         self.flat_grad = torch.zeros(o, dtype=torch.float32, device=self.device)
         self._flat = (order, offs, n1, n2, set(always), set(phase2), set(never))
         return self._flat
@@ -567,10 +575,12 @@ class VaeEngine(_StepBase):
                 self.assign_grads(phase2)
         return ls
 
-    def backward_rest(self):
+    def backward_rest(self, part="enc"):
+        """part: "enc" (all of it), or "enc_hi" (latents + coarse layers, their gradients final afterwards) then "enc_lo"."""
         w, phase2, eps, B, bp = self._bw_ctx
-        self._backward(w, phase2, eps, B, bp, part="enc")
-        self.assign_grads(phase2)
+        self._backward(w, phase2, eps, B, bp, part=part)
+        if part != "enc_hi":
+            self.assign_grads(phase2)
 
     def _backward(self, w, phase2, eps, B, bp, part="all"):
         hp, p, L = self.hp, self.p, self.p.L
@@ -582,7 +592,7 @@ class VaeEngine(_StepBase):
             if part == "dec":
                 self._join()
                 return
-        self._backward_encoder(w, phase2, eps, B, bp, enc_w, enc_b)
+        self._backward_encoder(w, phase2, eps, B, bp, enc_w, enc_b, part if part in ("enc_hi", "enc_lo") else "all")
 
     def _backward_decoder(self, w, phase2, bp, dconv):
         hp, p, L = self.hp, self.p, self.p.L
@@ -627,7 +637,24 @@ class VaeEngine(_StepBase):
                     (w["dH0"], "dec.latent_dec_layers.0.bias", "dlinb0", base, p.dec_feat[0], p.edge_num[L], p.dec_feat[0]))
         lin.backward_data(w["dH0"], w["dZ%d" % (L - 1)], bp)
 
-    def _backward_encoder(self, w, phase2, eps, B, bp, enc_w, enc_b):
+    def _backward_encoder(self, w, phase2, eps, B, bp, enc_w, enc_b, part="all"):
+        hp, p, L = self.hp, self.p, self.p.L
+        if part != "enc_lo":
+            self._backward_encoder_head(w, phase2, eps, B, bp)
+            lo_layer = self.enc_cut if part == "enc_hi" else 0
+            self._backward_encoder_layers(w, phase2, bp, enc_w, enc_b, L - 1, lo_layer)
+            if part == "enc_hi":
+                self._join()
+                return
+        else:
+            self._backward_encoder_layers(w, phase2, bp, enc_w, enc_b, self.enc_cut - 1, 0)
+        self._join()
+        if MULTI_REDUCE:
+            if self._multired is None:
+                self._multired = ops.MultiReduce(self.device)
+            self._multired.run(self._pending_red, self._pending_rs, bp)
+
+    def _backward_encoder_head(self, w, phase2, eps, B, bp):
         hp, p, L = self.hp, self.p, self.p.L
         # ---------------- reparametrisation + KL ----------------
         k, d = p.edge_num[L], p.lat_dim[L - 1]
@@ -643,7 +670,11 @@ class VaeEngine(_StepBase):
         self._wgrad(lin, w["dZD%d" % i], w["A%d" % i], "enc.latent_enc_layers.%d.weight" % i, bp, w,
                     (w["dZD%d" % i], "enc.latent_enc_layers.%d.bias" % i, ("elinb", i), base, 2 * d, k, 2 * d))
         lin.backward_data(w["dZD%d" % i], w["dA%d" % i], bp)
-        for i in range(L - 1, -1, -1):
+
+    def _backward_encoder_layers(self, w, phase2, bp, enc_w, enc_b, first, last):
+        """Encoder layers first, first-1, .., last (backward order)."""
+        hp, p, L = self.hp, self.p, self.p.L
+        for i in range(first, last - 1, -1):
             if i == 0 and phase2:
                 lin = self.enc_lin[0]
                 k0, d0 = p.edge_num[1], p.lat_dim[0]
@@ -676,11 +707,6 @@ class VaeEngine(_StepBase):
                 self._wgrad(conv, w["dY%d" % i], x, enc_w[i], bp, w, bias)
                 if i > 0:
                     conv.backward_data(w["dY%d" % i], w["dA%d" % (i - 1)], bp)
-        self._join()
-        if MULTI_REDUCE:
-            if self._multired is None:
-                self._multired = ops.MultiReduce(self.device)
-            self._multired.run(self._pending_red, self._pending_rs, bp)
 
     # ------------------------------------------------------------------------------------------
     # inference pieces (test()/gen_seq()/_decode)

@@ -46,11 +46,15 @@ class GraphedStep:
         self.data = tuple(lst)
         self.graphs = None
         self.g1b = None
+        self.g1c = None
         import os
         # HMVAE_DDP_SPLIT=0: one all-reduce after the whole backward.  HMVAE_FORCE_SPLIT=1: take the multi-graph path
         # on a single GPU too (tests / overhead measurement).
         self.split = os.environ.get("HMVAE_DDP_SPLIT", "1") != "0" and self.is_vae
         self.force_split = os.environ.get("HMVAE_FORCE_SPLIT", "0") == "1"
+        # HMVAE_DDP_BUCKETS=3 (default): the encoder's backward is cut once more -- coarse layers | fine layers -- so that
+        # only the fine layers' few MB are all-reduced exposed; 2: [decoder | encoder]
+        self.buckets = int(os.environ.get("HMVAE_DDP_BUCKETS", "3"))
         self._pinned = None
         self.phase2 = None
         self.warmup = warmup
@@ -79,8 +83,8 @@ class GraphedStep:
         eng = self.model.engine()
         self.losses = eng.train_step(self.r6, self.rmat, self.it, eps_list=None, backward=True, stage="dec")
 
-    def _bwd_enc(self):
-        self.model.engine().backward_rest()
+    def _bwd_enc(self, part="enc"):
+        self.model.engine().backward_rest(part)
 
     def _optim(self):
         self.tr.gen_opt.step()
@@ -96,11 +100,17 @@ class GraphedStep:
         eng = self.model.engine()
         return ddp.all_reduce_sum_async(eng.flat_grad[:eng.n_dec_floats])
 
-    def _reduce_enc_and_finish(self, handle):
+    def _reduce_hi_async(self):
+        """The coarse encoder half's slice, asynchronous beside the fine layers' backward (queued behind the decoder's)."""
+        eng = self.model.engine()
+        return ddp.all_reduce_sum_async(eng.flat_grad[eng.n_dec_floats:eng.n_hi_floats])
+
+    def _reduce_enc_and_finish(self, handles, start=None):
         eng = self.model.engine()
         n = eng.active_grad_floats(self.phase2)
-        ddp.all_reduce_sum_(eng.flat_grad[eng.n_dec_floats:n])
-        ddp.wait(handle)
+        ddp.all_reduce_sum_(eng.flat_grad[eng.n_dec_floats if start is None else start:n])
+        for h in handles:
+            ddp.wait(h)
         ddp.scale_(eng.flat_grad[:n])
 
     def _phase2(self):
@@ -121,10 +131,10 @@ class GraphedStep:
         torch.cuda.synchronize()
         if self.graphs is not None:
             retire(*self.graphs)
-        retire(self.g1b)
+        retire(self.g1b, self.g1c)
         g1 = torch.cuda.CUDAGraph()
         g2 = None
-        self.g1b = None
+        self.g1b = self.g1c = None
         if ddp.is_distributed() or self.force_split:
             if self.split:
                 # three graphs: [forward + decoder backward] -> async all-reduce of the decoder gradients ||
@@ -132,8 +142,15 @@ class GraphedStep:
                 with torch.cuda.graph(g1):
                     self._fwd_bwd_dec()
                 self.g1b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g1b):
-                    self._bwd_enc()
+                if self.buckets >= 3:
+                    with torch.cuda.graph(self.g1b):
+                        self._bwd_enc("enc_hi")
+                    self.g1c = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.g1c):
+                        self._bwd_enc("enc_lo")
+                else:
+                    with torch.cuda.graph(self.g1b):
+                        self._bwd_enc()
             else:
                 with torch.cuda.graph(g1):
                     self._fwd_bwd()
@@ -156,7 +173,7 @@ class GraphedStep:
         try:
             if self.graphs is not None:
                 retire(*self.graphs)
-            retire(self.g1b)
+            retire(self.g1b, self.g1c)
         except Exception:
             pass
 
@@ -177,10 +194,17 @@ class GraphedStep:
         g1.replay()
         if g2 is not None:
             if self.g1b is not None:
-                h = self._reduce_dec_async() if ddp.is_distributed() else None
+                dist = ddp.is_distributed()
+                hs = [self._reduce_dec_async()] if dist else []
                 self.g1b.replay()
-                if ddp.is_distributed():
-                    self._reduce_enc_and_finish(h)
+                start = None
+                if self.g1c is not None:
+                    if dist:
+                        hs.append(self._reduce_hi_async())
+                        start = self.model.engine().n_hi_floats
+                    self.g1c.replay()
+                if dist:
+                    self._reduce_enc_and_finish(hs, start)
             else:
                 self._reduce()
             g2.replay()

@@ -84,8 +84,22 @@ def _worker(rank, world, port, tag, phase2, out_dir):
     ddp.all_reduce_sum_(two[nd:nfl])
     ddp.wait(h)
     ddp.scale_(two[:nfl])
+    # the three-bucket path: [decoder | coarse encoder half + deep latent head | fine encoder layers (+ phase-2 head)]
+    three = eng.flat_grad.clone()
+    nh = eng.n_hi_floats
+    hi_names = ["enc.layers.%d.0.weight" % i for i in range(eng.enc_cut, eng.p.L)] + \
+        ["enc.latent_enc_layers.%d.weight" % (eng.p.L - 1)]
+    lo_names = ["enc.layers.%d.0.weight" % i for i in range(eng.enc_cut)] + ["enc.latent_enc_layers.0.weight"]
+    assert nd < nh < nfl and all(nd <= offs[nm] < nh for nm in hi_names) and all(offs[nm] >= nh for nm in lo_names)
+    h1 = ddp.all_reduce_sum_async(three[:nd])
+    h2 = ddp.all_reduce_sum_async(three[nd:nh])
+    ddp.all_reduce_sum_(three[nh:nfl])
+    ddp.wait(h1)
+    ddp.wait(h2)
+    ddp.scale_(three[:nfl])
     ddp.all_reduce_mean_(eng.flat_grad[:nfl])
     assert torch.allclose(two, eng.flat_grad, rtol=1e-6, atol=0)
+    assert torch.allclose(three, eng.flat_grad, rtol=1e-6, atol=0)
     assert torch.equal(eng.flat_grad[nfl:], tail_before)          # tensors without gradient are not communicated
     if rank == 0:
         ref = O.OracleVAE(cfg, seeded, offsets=offsets())

@@ -24,16 +24,15 @@ def main():
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--cpu-iters", type=int, default=2)
     a = ap.parse_args()
-    from hm_vae_amd import refine
+    from hm_vae_amd import my_tools, refine
     from hm_vae_amd.trainer_motion_vae import Trainer
-    from oracle import hmvae_oracle as O
     cfg = yaml.safe_load(open(a.config))
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     tr = Trainer(cfg)
     tr.cuda()
     B, T = a.windows, cfg["train_seq_len"]
-    target = O.rot6d_to_matrix(torch.randn(B * T * 24, 6)).reshape(B, T, 24, 3, 3)
+    target = my_tools.rotation_matrix_from_ortho6d(torch.randn(B * T * 24, 6, device=dev)).reshape(B, T, 24, 3, 3)
     mask = torch.from_numpy(refine.temporal_mask(T, cfg["interpolation_window"]))[None, :, None].repeat(B, 1, 24)
     out = {"windows": B, "T": T}
     for phase, after in (("latent", 10 ** 9), ("decoder", -1)):
@@ -49,7 +48,9 @@ def main():
         dt = (time.perf_counter() - t0) / a.iters
         ref.restore()
         out[phase] = {"ms_per_iter": dt * 1e3, "window_iters_per_s": B / dt}
-    if a.cpu_iters:
+    if a.cpu_iters:                               # the CPU leg: the oracle's restatement of one iteration
+        from oracle import hmvae_oracle as O
+        target, mask = target.cpu(), mask.cpu()
         offs = tr.model.fk_layer.positions[0].cpu().numpy()
         sd = {k: v.detach().cpu() for k, v in tr.model.state_dict().items()}
         orc = O.OracleVAE(cfg, sd, offsets=offs)
