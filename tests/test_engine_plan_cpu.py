@@ -93,3 +93,18 @@ def test_c_abi_exports_match_header():
     d = _lib.GemmDesc()
     import ctypes as C
     assert lib.hmvae_gather_gemm(C.byref(d), None) == -1
+
+
+def test_retired_graphs_are_parked_not_destroyed():
+    """graph_step.retire keeps replaced graphs alive (destroying a multi-stream hipGraph corrupts the runtime's heap on
+    this ROCm release); callers that capture per work item stop capturing at MAX_RETIRED."""
+    from hm_vae_amd import graph_step
+    before = list(graph_step._RETIRED)
+    try:
+        a, b = object(), object()
+        graph_step.retire(a, None, b)
+        assert graph_step._RETIRED[-2:] == [a, b] and graph_step.may_capture()
+        graph_step._RETIRED.extend([object()] * graph_step.MAX_RETIRED)
+        assert not graph_step.may_capture()
+    finally:
+        graph_step._RETIRED[:] = before
