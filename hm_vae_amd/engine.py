@@ -206,7 +206,8 @@ class VaeEngine(_StepBase):
         # ---- decoder ops ----
         self.dec_conv, self.dec_unpool, self.dec_lin = [], [], {}
         self.cD = p.dec_cout[L - 2] // p.edge_num[1]          # running channels per edge before the concat
-        self.enc_cut = L // 2                                 # encoder layers >= enc_cut: the coarse half (grad bucket / backward cut)
+        # encoder layers >= enc_cut: the coarse half (gradient bucket / backward cut of the DDP step)
+        self.enc_cut = min(max(int(_os0.environ.get("HMVAE_ENC_CUT", L // 2)), 1), L - 1) if L > 1 else 0
         self.cH = p.ch_base[1]                                # skip (hier_feats[L-1]) channels per edge
         assert p.dec_cin[L - 1] // p.edge_num[0] == self.cD + self.cH
         for i in range(L):
