@@ -6,6 +6,12 @@ Start from the autotuner's alone-timed picks, then coordinate descent: one knob 
 kernels' (column units, K split), the weight-gradient GEMMs' (split, direct / LDS-staged) -- the whole hipGraph step is
 re-captured and timed, a candidate is kept when it beats the incumbent by more than the measurement noise.  The result
 is written in the autotune-cache format (keys name shape and batch) and merged into the output file.
+
+Replaced graphs are parked, not destroyed (graph_step.retire: the destroy path corrupts the runtime's heap).  With many
+hundred parked graphs replays slow down (seen once: 1.81 -> 3.96 ms/step at the start of a second pass after ~700 graphs), so
+later candidates then only lose against the incumbent and the pass ends without changes: run one pass per process for big
+sweeps.  HMVAE_FORCE_SPLIT=1 tunes the four-graph DDP step: starting from the shipped choices it found < 1 % (1.825 ->
+1.809 ms), so there is no separate file for it.
 """
 import argparse
 import json
