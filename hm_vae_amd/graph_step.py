@@ -16,7 +16,7 @@ from . import ddp
 # did not change it.  A training run re-captures once (phase switch), a refinement loop captures two graphs per window
 # batch: they are parked here (host memory: a few hundred KB each).
 _RETIRED = []
-MAX_RETIRED = 256
+MAX_RETIRED = 64
 
 
 def retire(*graphs):
