@@ -224,8 +224,9 @@ def test_full_loop_interpolates_and_restores(dev):
 
 def test_graph_replay_equals_eager(dev, monkeypatch):
     """The per-phase hipGraph replay runs the same launches as the eager loop: same loss history, same result."""
-    from hm_vae_amd import refine
+    from hm_vae_amd import graph_step, refine
     monkeypatch.setattr(refine, "DECODER_PHASE_AFTER", 3)
+    monkeypatch.setattr(graph_step, "MAX_RETIRED", 10 ** 6)      # (a long test session may have parked its quota already)
     cfg = interp_cfg()
     model, plan, seeded = make_model(cfg, dev)
     B, T = 1, cfg["train_seq_len"]                    # the reference's batch: one window
