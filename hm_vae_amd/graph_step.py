@@ -116,9 +116,44 @@ class GraphedStep:
     def _phase2(self):
         return self.is_vae and self.it >= self.cfg['iteration_interval']
 
+    def _snapshot(self):
+        opt = self.tr.gen_opt
+        params = [p for g in opt.param_groups for p in g['params']]
+        state = {}
+        for p in params:
+            st = opt.state.get(p)
+            if st:
+                state[p] = (st['exp_avg'].clone(), st['exp_avg_sq'].clone(), opt._host_step.get(p, 0))
+        return [p.detach().clone() for p in params], params, state
+
+    def _restore(self, snap):
+        values, params, state = snap
+        opt = self.tr.gen_opt
+        with torch.no_grad():
+            for p, v in zip(params, values):
+                p.copy_(v)
+            for p in params:
+                st = opt.state.get(p)
+                if not st:
+                    continue
+                if p in state:
+                    st['exp_avg'].copy_(state[p][0])
+                    st['exp_avg_sq'].copy_(state[p][1])
+                    opt._host_step[p] = state[p][2]
+                else:                                  # created by the warm-up: back to "never stepped"
+                    st['exp_avg'].zero_()
+                    st['exp_avg_sq'].zero_()
+                    opt._host_step[p] = 0
+        for ent in opt._cache.values():                # device step counters follow the host mirror again
+            ent['host'] = opt._host_step[ent['params'][0]]
+            ent['step'].fill_(ent['host'])
+
     def _capture(self):
         self.phase2 = self._phase2()
         # warm up eagerly on a side stream: creates workspaces, index tables and the Adam state outside the graph
+        # (the warm-up steps are real optimiser steps: parameters and Adam state are put back afterwards, so a run with
+        # graph replay takes exactly the steps an eager run takes)
+        snap = self._snapshot()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -129,6 +164,7 @@ class GraphedStep:
                 self.tr.gen_opt.advance_host_steps(0)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        self._restore(snap)
         if self.graphs is not None:
             retire(*self.graphs)
         retire(self.g1b, self.g1c)

@@ -76,6 +76,25 @@ class Trainer(nn.Module):
         vals = torch.stack([getattr(self, prefix + n).reshape(()) for n in _LOSS_NAMES]).tolist()
         return tuple(vals)
 
+    def gen_update_graph(self, data, hp, iterations, multigpus=False):
+        """gen_update with the step replayed from a hipGraph (graph_step.GraphedStep: forward, backward, gradient
+        all-reduce slices and the optimiser as a fixed launch sequence; re-captured at the phase switch).  Same nine floats;
+        the `loss_*` attributes hold python floats.  A batch of another size than the captured one takes the eager path."""
+        from .graph_step import GraphedStep
+        gs = getattr(self, "_graphed", None)
+        B = data[0].shape[0]
+        if gs is not None and gs.r6.shape[0] != B:
+            return self.gen_update(data, hp, iterations, multigpus)
+        if gs is None:
+            gs = self._graphed = GraphedStep(self, hp, data, iterations)
+        else:
+            gs.set_batch(data)
+            gs.it = int(iterations)
+        out = gs.run()
+        for name, val in zip(_LOSS_NAMES, out):
+            setattr(self, "loss_" + name, val)
+        return out
+
     def resume(self, checkpoint_dir, hp, multigpus):
         this_model = self._this_model()
         last_model_name = get_model_list(checkpoint_dir, "gen")

@@ -302,3 +302,48 @@ def test_bench_two_rank_launch_rehearsal(dev, tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["scaling"] == "weak"
     assert out["value"] > 0 and np.isfinite(out["loss_total"]) and "roofline" not in out
+
+
+def test_graph_replay_across_the_phase_switch(dev):
+    """At iterations == iteration_interval the shallow latent head starts to train (seq_two_hier_sa_vae.py:371-383): the
+    step is re-captured with the larger live set (the replaced graphs are parked, graph_step.retire).  Graph replay and
+    eager launches must agree on every step across the switch.  kl_w = 0 makes the step deterministic (z = mu, no noise)."""
+    from hm_vae_amd import graph_step
+    from hm_vae_amd.graph_step import GraphedStep
+    g, meta = load_model_golden("len8")
+    batch = golden_batch(g)
+    outs = []
+    for use_graph in (False, True):
+        cfg, plan, tr, seeded = make_trainer("len8", dev)
+        cfg = dict(cfg, kl_w=0.0, shallow_kl_w=0.01, iteration_interval=3)
+        tr.model.hp.update(kl_w=0.0, shallow_kl_w=0.01, iteration_interval=3)
+        tr.model.iteration_interval = 3
+        tr.model._engine = None
+        parked = len(graph_step._RETIRED)
+        step = GraphedStep(tr, cfg, batch, 0, use_graph=use_graph, warmup=1)
+        losses = [step.run() for _ in range(7)]
+        if use_graph:
+            assert step.phase2 and len(graph_step._RETIRED) > parked          # re-captured once, old graphs parked
+        head = tr.model.state_dict()["enc.latent_enc_layers.0.weight"].detach().cpu().numpy().copy()
+        params = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters() if p.requires_grad]).cpu().numpy()
+        outs.append((np.array(losses), params, head))
+        assert np.abs(head - seeded["enc.latent_enc_layers.0.weight"].numpy()).max() > 0     # it did start to train
+    assert rel_err(outs[1][0][:, :5], outs[0][0][:, :5]) < 5e-4
+    # seven Adam steps of 1e-4 each: a parameter whose gradient is rounding noise moves by +-lr per step in either run
+    # (two engines, each with its own kernel variants), so compare at the size of one step, not of the noise
+    frac_close = float((np.abs(outs[1][1] - outs[0][1]) < 1e-4).mean())
+    assert frac_close > 0.999, frac_close
+
+
+def test_cli_with_graph_replay(dev, tmp_path):
+    """train_motion_vae.py --graph: the same loop with Trainer.gen_update_graph (capture on the first batch, replay after)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "train_motion_vae.py"), "--config",
+           os.path.join(root, "configs", "len8_data_aug_hm_vae.yaml"), "--output_path", str(tmp_path), "--batch_size", "4",
+           "--max_iter", "6", "--graph"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Training: Total loss" in r.stdout and "Finish Training" in r.stdout

@@ -37,6 +37,7 @@ def main():
     parser.add_argument('--batch_size', type=int, default=0, help="override the YAML batch_size (per process)")
     parser.add_argument('--max_iter', type=int, default=0, help="override the YAML max_iter")
     parser.add_argument('--data_folder', type=str, default='', help="directory of T x 579 npy sequences")
+    parser.add_argument('--graph', action="store_true", help="replay the training step from a hipGraph (not in the reference)")
     opts = parser.parse_args()
 
     config = get_config(opts.config)
@@ -73,7 +74,10 @@ def main():
         for it, input_data in enumerate(train_loader):
             if world > 1 and input_data[0].shape[0] == config['batch_size'] * world:
                 input_data = ddp.shard_batch(input_data, rank, world)
-            out = trainer.gen_update(input_data, config, iterations, opts.multigpus)
+            if opts.graph:
+                out = trainer.gen_update_graph(input_data, config, iterations, opts.multigpus)
+            else:
+                out = trainer.gen_update(input_data, config, iterations, opts.multigpus)
             if it % 50 == 0 and rank == 0:
                 print('Training: Total loss: %.4f, KL loss: %.8f, Rec 6D loss: %.4f, Rec Rot loss: %.4f, Rec Pose loss: %.4f, '
                       'Rec joint pos loss: %.4f, Rec root v loss: %.4f, Rec linear v loss: %.4f, Rec angular v loss: %.4f' % out)
