@@ -268,8 +268,7 @@ def test_traj_graph_replay_matches_eager(dev):
     cfg2, _, tr_g, _ = make_trainer(40, dev)
     gs = GraphedStep(tr_g, cfg2, batch, 0, use_graph=True, warmup=2)
     other = O.synthetic_traj_batch(3, 40, seed=12)
-    for s in range(2):                           # the capture is preceded by `warmup` real steps on the first batch
-        tr_e.gen_update(batch, cfg, s, False)
+    # (the capture's warm-up steps are undone -- parameters and Adam state restored -- so both runs take the same steps)
     eager, graph = [], []
     for s in range(4):
         b = batch if s % 2 == 0 else other
