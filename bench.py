@@ -162,59 +162,162 @@ def fk_microbench(device, iters=20):
     avg2 = timed(lambda: ops.fk_fwd(rot, 9, off, 0, par, n, None, pos))
     r6 = c6.reshape(n, 24, 6)
     avg3 = timed(lambda: ops.fk_fwd(r6, 6, off, 0, par, n, None, pos))
+    # backward of the fused lift + FK (6D 576 + dR 864 + dpos 288 read, d6D 576 written = 2 304 B/frame)
+    dR = torch.randn(n, 24, 9, device=device)
+    dP = torch.randn(n, 24, 3, device=device)
+    d6 = torch.empty(n, 24, 6, device=device)
+    avg4 = timed(lambda: ops.fk_bwd(r6, 6, off, 0, par, n, dR, dP, d6))
+    del dR, dP, d6
+    # the training step's tail at the same frame count: 6D -> R -> FK -> three MSEs and their backward in one launch
+    # (decoder output 576 + targets 576 + 864 + 288 read, d(decoder output) 576 written = 2 880 B/frame)
+    g6, gR, gP = (torch.randn(c * T, bp, device=device) for c in (144, 216, 72))
+    ddec = torch.empty(144 * T, bp, device=device)
+    part = torch.zeros(ops.decode_tail_loss_blocks(T, B, bp), 3, device=device)
+    avg5 = timed(lambda: ops.decode_tail_loss(dec, g6, gR, gP, off, T, B, bp, 1.0 / n, 1.0 / n, 1.0 / n, ddec, part))
+    del g6, gR, gP, ddec
 
     def gbs(bytes_per_frame, ms):
         return bytes_per_frame * n / (ms * 1e-3) / 1e9
 
+    def traffic_of(kernel):
+        """HBM-side bytes per launch from the committed PMC passes of tools/profile_fk.sh (None if absent)."""
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fk_traffic.json")))
+        if not files:
+            return None
+        k = json.load(open(files[-1])).get("kernels", {}).get(kernel)
+        return None if not k else k["traffic_bytes_per_launch"]
+
+    def entry(kernel, bytes_per_frame, ms, note=None):
+        e = {"kernel": kernel, "bytes_per_frame": bytes_per_frame, "avg_us": ms * 1e3, "achieved": gbs(bytes_per_frame, ms),
+             "frac": gbs(bytes_per_frame, ms) / PEAK_HBM_GBS, "traffic": traffic_of(kernel)}
+        if note:
+            e["note"] = note
+        return e
+
     return {"kernel": "decode_tail_fwd_kernel<false>", "frames": n, "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
             "achieved": gbs(fused_bytes, avg), "frac": gbs(fused_bytes, avg) / PEAK_HBM_GBS,
-            "bytes_per_frame_algorithmic": fused_bytes, "avg_us": avg * 1e3, "traffic": None,
+            "bytes_per_frame_algorithmic": fused_bytes, "avg_us": avg * 1e3,
+            "traffic": traffic_of("decode_tail_fwd_kernel<false>"),
+            "fk_bwd_aos": entry("fk_bwd_aos_kernel<6>", 2304, avg4, "backward of the fused lift + FK, frame-major"),
+            "tail_loss": entry("decode_tail_loss_kernel<false>", 2880, avg5,
+                               "training tail (lift + FK + 3 MSE + their backward) at config 4's frame count"),
             "note": "6D (SoA) in, R + positions (frame-major) out: the bytes moved are the algorithmic 1728 B/frame",
             "with_6d_copy": {"kernel": "decode_tail_fwd_kernel<true>", "bytes_per_frame_moved": 2304, "avg_us": avg_c6 * 1e3,
                              "achieved_moved": gbs(2304, avg_c6), "frac_moved": gbs(2304, avg_c6) / PEAK_HBM_GBS,
-                             "note": "_decode also returns the frame-major copy of the 6D input: 576 B/frame more to write"},
+                             "achieved": gbs(fused_bytes, avg_c6), "frac": gbs(fused_bytes, avg_c6) / PEAK_HBM_GBS,
+                             "traffic": traffic_of("decode_tail_fwd_kernel<true>"),
+                             "note": "_decode also returns the frame-major copy of the 6D input: 576 B/frame more to "
+                                     "write; achieved / frac count SURVEY's 1728 algorithmic bytes only"},
             "fk_only_aos": {"kernel": "fk_fwd_aos_kernel<9>", "bytes_per_frame": 1152, "avg_us": avg2 * 1e3,
                             "achieved": gbs(1152, avg2), "frac": gbs(1152, avg2) / PEAK_HBM_GBS},
             "fk_rot6d_aos": {"kernel": "fk_fwd_aos_kernel<6>", "bytes_per_frame": 864, "avg_us": avg3 * 1e3,
                              "achieved": gbs(864, avg3), "frac": gbs(864, avg3) / PEAK_HBM_GBS}}
 
 
-def cpu_baseline(cfg, budget_s=20.0):
-    """The CPU oracle's full training step (fwd + bwd + Adam) on the host cores; bounded sample."""
+def _host_cores():
+    """(usable logical CPUs of this process, physical cores among them)."""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    phys = usable
+    try:
+        import psutil
+        phys = min(usable, psutil.cpu_count(logical=False) or usable)
+    except Exception:
+        pass
+    # a container's CPU share (cgroup quota) is what the box really grants: more threads than that only oversubscribe
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            quota = float(txt[0])
+            period = float(txt[1]) if len(txt) > 1 else float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                usable = max(1, min(usable, int(round(quota / period))))
+                phys = min(phys, usable)
+        except (OSError, ValueError, IndexError):
+            pass
+    return usable, phys
+
+
+def cpu_baseline(cfg, budget_s=28.0):
+    """The CPU oracle's full training step (fwd + bwd + Adam, SURVEY 8(d) "CPU baseline") on the host cores: a thread
+    sweep at B=64 (1 / 8 / 16 / 32 / physical / usable cores), then B=256 at the best thread count.  Bounded: every
+    point gets one warm-up step and then timed steps until its share of the budget is used (a point whose warm-up alone
+    exceeds its share reports that step).  `value` is the best sequences/s found; the 1-thread figure sits beside it."""
     import numpy as np
     from oracle import hmvae_oracle as O
-    B = 64
     plan = O.Plan(cfg)
     off = np.load(os.path.join(ROOT, "hm_vae_amd", "assets", "skeleton_offsets.npy"))
-    m = O.OracleVAE(cfg, O.name_seeded_params(plan), offsets=off)
-    opt, sched = O.make_adam(m, cfg)
-    batch = O.synthetic_batch(B, cfg["train_seq_len"], seed=0)
     it = cfg["iteration_interval"]
-    times = []
-    t_start = time.time()
-    n = 0
-    while True:
-        t0 = time.time()
-        opt.zero_grad()
-        m.train_forward(batch, it, O.level_eps(plan, B, seed=n))
-        opt.step()
-        dt = time.time() - t0
-        if n >= 1:
-            times.append(dt)
-        n += 1
-        if (time.time() - t_start > budget_s and len(times) >= 2) or len(times) >= 20:
-            break
-    avg = sum(times) / len(times)
-    return {"value": B / avg, "unit": "sequences/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d timed steps of the pure-PyTorch CPU oracle (fwd+bwd+Adam), len64 config, B=%d, after 1 warm-up"
-                      % (len(times), B), "ms_per_step": avg * 1e3}
+    usable, phys = _host_cores()
+    sweep = sorted(set(t for t in (1, 8, 16, 32, phys, usable) if 1 <= t <= usable))
+    was = torch.get_num_threads()
+
+    def point(threads, B, share):
+        torch.set_num_threads(threads)
+        m = O.OracleVAE(cfg, O.name_seeded_params(plan), offsets=off)
+        opt, sched = O.make_adam(m, cfg)
+        batch = O.synthetic_batch(B, cfg["train_seq_len"], seed=0)
+        times = []
+        t_start = time.time()
+        n = 0
+        while True:
+            t0 = time.time()
+            opt.zero_grad()
+            m.train_forward(batch, it, O.level_eps(plan, B, seed=n))
+            opt.step()
+            times.append(time.time() - t0)
+            n += 1
+            if time.time() - t_start > share or n >= 6:
+                break
+        timed = times[1:] if len(times) > 1 else times
+        avg = sum(timed) / len(timed)
+        return {"threads": threads, "batch": B, "sequences_per_s": B / avg, "ms_per_step": avg * 1e3,
+                "timed_steps": len(timed), "warm": len(times) > 1}
+
+    share = budget_s / (len(sweep) + 3.0)            # B=256 costs ~4x: it gets three shares
+    points = [point(t, 64, share) for t in sweep]
+    best = max(points, key=lambda r: r["sequences_per_s"])
+    big = point(best["threads"], 256, 3.0 * share)
+    torch.set_num_threads(was)
+    top = max([best, big], key=lambda r: r["sequences_per_s"])
+    one = next(r for r in points if r["threads"] == 1)
+    return {"value": top["sequences_per_s"], "unit": "sequences/s", "cores": top["threads"], "kind": "port",
+            "sample": "pure-PyTorch CPU oracle, len64 config, fwd+bwd+Adam: thread sweep %s at B=64 (one warm-up + up to 5 "
+                      "timed steps per point, ~%.0f s each), then B=256 at the best thread count; value = best point "
+                      "(B=%d, %d threads)" % (sweep, share, top["batch"], top["threads"]),
+            "ms_per_step": top["ms_per_step"], "batch": top["batch"],
+            "one_thread": {"value": one["sequences_per_s"], "batch": 64, "ms_per_step": one["ms_per_step"]},
+            "b64_best": best, "b256_best_threads": big, "sweep": points,
+            "host": {"usable_cpus": usable, "physical_cores": phys, "logical_cpus": os.cpu_count()}}
+
+
+def self_launch(n):
+    """Re-run this command line as N ranks of torch.distributed.run on 127.0.0.1 (a free port); returns its exit code."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()            # counting devices does not initialise the GPU
+    if n_dev < n and os.environ.get("HMVAE_SINGLE_DEVICE", "0") != "1":
+        sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s)\n" % (n, n_dev))
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="sequences per GPU")
     ap.add_argument("--config", type=str, default=os.path.join(ROOT, "configs", "len64_no_aug_hm_vae.yaml"))
     ap.add_argument("--phase", type=int, default=2, choices=(1, 2))
@@ -225,7 +328,13 @@ def main():
     ap.add_argument("--sync-losses", type=int, default=0,
                     help="1: block on every step's loss read-back (like the reference's .item() calls); 0: the read-back "
                          "lags one step (pinned buffer + event), so the host queues step n+1 while step n runs")
+    ap.add_argument("--no-phase1", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` run plainly: become the launcher.  N ranks through torch.distributed.run (one
+        # process per GPU, RCCL), started BEFORE anything here touches the GPU; this process only relays the exit code.
+        return self_launch(args.gpus)
 
     from hm_vae_amd import ddp, _lib
     from hm_vae_amd.trainer_motion_vae import Trainer
@@ -233,8 +342,12 @@ def main():
     from hm_vae_amd.graph_step import GraphedStep
 
     rank, world, local = ddp.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        # never measure fewer GPUs than asked for and print it as if it were the request
+        sys.stderr.write("bench.py: --gpus %d but the launch has WORLD_SIZE=%d\n" % (args.gpus, world))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return 2
     _lib.require_gpu()
     # HMVAE_SINGLE_DEVICE=1 (with HMVAE_DIST_BACKEND=gloo): every rank on cuda:0 -- a control-flow rehearsal of the N > 1
     # launch on a one-GPU box, not a measurement
@@ -285,6 +398,32 @@ def main():
                       "loss_readback": "every step, lagging one step (non-blocking)" if lag else "every step, blocking"},
            "loss_total": float(step.last_losses()[0]) if lag else float(losses[0])}
 
+    if not args.no_phase1 and args.phase == 2:
+        # SURVEY 8(d) "report phase 1 too": iterations < iteration_interval -- the shallow latent head is detached
+        # (seq_two_hier_sa_vae.py:380-385), two fewer tensors in the bucket.  Same trainer, same batch, every rank;
+        # its own capture, a shorter timed run bracketed like the headline.
+        step1 = GraphedStep(tr, cfg, data, 0, use_graph=bool(args.graph))
+        k1 = max(10, args.steps // 2)
+        for _ in range(max(3, args.warmup // 2)):
+            step1.run()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        t1 = time.perf_counter()
+        for _ in range(k1):
+            step1.run(lag=lag)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        e1 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([e1], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            e1 = float(t.item())
+        out["phase1"] = {"value": B * world * k1 / e1, "unit": "sequences/s", "ms_per_step": e1 / k1 * 1e3, "steps": k1,
+                         "note": "iterations < iteration_interval: level-0 latent branch detached"}
+        del step1
+
     # N = 1 only: the extra eager steps below go through Trainer.gen_update, whose gradient all-reduce is a collective --
     # rank 0 alone must not enter it
     if rank == 0 and world == 1 and not args.no_kernel_timing:
@@ -334,7 +473,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

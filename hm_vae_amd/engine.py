@@ -83,6 +83,11 @@ class _StepBase:
         # fewer streams than chains the round-robin makes late layers queue behind unrelated early chains.
         self.n_side = int(_os.environ.get("HMVAE_SIDE_STREAMS", "16"))
         self._turn = 0
+        self._forked = set()              # side streams forked since the last join
+        # HMVAE_JOIN_ALL=1: round-1 behaviour, kept for the A/B of tools/repro -- the join also records and waits events on
+        # side streams that were never forked in this step (inside a stream capture that is an eager record on a stream
+        # outside the capture, waited on by the capturing stream)
+        self._join_all = _os.environ.get("HMVAE_JOIN_ALL", "0") == "1"
         self._pending_red, self._pending_rs = [], []
         self._events = {}
         self._skip_wgrad = False          # test-time optimisation of the latents alone: data gradients only
@@ -131,13 +136,16 @@ class _StepBase:
         self._turn = (self._turn + 1) % self.n_side
         side = self._side[self._turn]
         self._stream_wait(side, main, ("fork", self._turn))
+        self._forked.add(self._turn)
         return torch.cuda.stream(side)
 
     def _join(self):
+        """The main stream waits for every side stream forked since the last join (and only those)."""
         if self.overlap and self._side is not None:
             main = torch.cuda.current_stream()
-            for i, s in enumerate(self._side):
-                self._stream_wait(main, s, ("join", i))
+            for i in (range(self.n_side) if self._join_all else sorted(self._forked)):
+                self._stream_wait(main, self._side[i], ("join", i))
+        self._forked.clear()
 
     def _wgrad(self, op, dy, x, name, bp, w, bias=None, before=None):
         """bias: optional (src, grad_name, rows_key, base, n_out, rows_per_out, row_step) for the row-sum kernel.

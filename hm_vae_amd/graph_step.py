@@ -19,13 +19,20 @@ _RETIRED = []
 MAX_RETIRED = 64
 
 
+import os as _os
+PARK = _os.environ.get("HMVAE_GRAPH_PARK", "1") != "0"
+
+
 def retire(*graphs):
-    _RETIRED.extend(g for g in graphs if g is not None)
+    if PARK:
+        _RETIRED.extend(g for g in graphs if g is not None)
+    elif any(g is not None for g in graphs):
+        torch.cuda.synchronize()            # nothing of the graph is in flight when its last reference goes
 
 
 def may_capture():
     """False once MAX_RETIRED graphs are parked: callers that create graphs per work item fall back to eager launches."""
-    return len(_RETIRED) < MAX_RETIRED
+    return (not PARK) or len(_RETIRED) < MAX_RETIRED
 
 
 class GraphedStep:

@@ -53,6 +53,11 @@ TUNE_CACHE = _os.environ.get("HMVAE_TUNE_CACHE")
 TUNE_DEFAULTS = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "assets", "tune_mi355x.json")
 _tune_defaults = None
 _tune_cache = None
+# Choices made in this process, keyed like the cache file: a second engine for the same problem (validation model, a
+# re-built trainer, the tests' eager / graph pairs) launches the SAME kernel variants as the first -- same summation
+# order, bit-identical results -- and skips the timing runs.  HMVAE_TUNE_MEMO=0 times every engine afresh.
+_tune_memo = {}
+TUNE_MEMO = _os.environ.get("HMVAE_TUNE_MEMO", "1") != "0"
 
 
 def _tune_default_get(key):
@@ -70,6 +75,8 @@ def _tune_default_get(key):
 
 def _tune_cache_get(key):
     global _tune_cache
+    if TUNE_MEMO and key in _tune_memo:
+        return _tune_memo[key]
     if TUNE_CACHE is None:
         return _tune_default_get(key)
     if _tune_cache is None:
@@ -83,6 +90,8 @@ def _tune_cache_get(key):
 
 
 def _tune_cache_put(key, val):
+    if TUNE_MEMO:
+        _tune_memo[key] = list(val)
     if TUNE_CACHE is None:
         return
     import json

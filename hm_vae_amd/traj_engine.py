@@ -201,6 +201,7 @@ class TrajEngine(_StepBase):
         p, T = self.p, self.p.T
         enc_w, enc_b = self.names()
         L = p.L
+        self._turn = 0                          # the same chain -> stream assignment every step
         base = (np.arange(3) * T).astype(np.int32)
         self._wgrad(self.head, w["dV"], w["A%d" % (L - 1)], "fc_mapping.weight", bp, w,
                     (w["dV"], "fc_mapping.bias", "headb", base, 3, T, 1))

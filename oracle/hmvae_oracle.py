@@ -320,24 +320,29 @@ class OracleVAE:
     `params` maps reference state_dict names to leaf tensors (requires_grad as needed).
     """
 
-    def __init__(self, hp, params=None, parents=SMPL24_PARENTS, offsets=None):
+    def __init__(self, hp, params=None, parents=SMPL24_PARENTS, offsets=None, dtype=torch.float32):
+        """dtype: float32 is the reference's arithmetic (what the golden vectors pin); float64 evaluates the SAME graph
+        in double precision -- the yardstick for gradients whose fp32 evaluation error (the reference's own included)
+        is comparable to the parity tolerance."""
         self.hp = hp
+        self.dtype = dtype
         self.plan = Plan(hp, parents)
         self.parents = list(parents)
         if offsets is None:
             raise ValueError("offsets (J,3) required")
-        self.offsets = torch.as_tensor(offsets, dtype=torch.float32)
-        self.masks = oracle_masks(self.plan)
+        self.offsets = torch.as_tensor(offsets, dtype=torch.float32).to(dtype)
+        self.masks = {k: v.to(dtype) for k, v in oracle_masks(self.plan).items()}
         p = self.plan
-        self.pool_w = [pool_matrix(p.pooling[i], p.edge_num[i], p.enc_cout[i] // p.edge_num[i]) for i in range(p.L)]
-        self.unpool_w = [unpool_matrix(p.pooling[p.L - 1 - i], p.dec_cin[i] // p.edge_num[p.L - 1 - i])
+        self.pool_w = [pool_matrix(p.pooling[i], p.edge_num[i], p.enc_cout[i] // p.edge_num[i]).to(dtype)
+                       for i in range(p.L)]
+        self.unpool_w = [unpool_matrix(p.pooling[p.L - 1 - i], p.dec_cin[i] // p.edge_num[p.L - 1 - i]).to(dtype)
                          for i in range(p.L)]
         self.params = {}
         if params is not None:
             self.load(params)
 
     def load(self, params):
-        self.params = {k: v.detach().clone().float().requires_grad_(True) for k, v in params.items()
+        self.params = {k: v.detach().clone().to(self.dtype).requires_grad_(True) for k, v in params.items()
                        if k in reference_param_shapes(self.plan)}
 
     def trainable(self):
@@ -423,7 +428,8 @@ class OracleVAE:
         Returns a dict with every intermediate the parity tests compare.
         """
         hp, p = self.hp, self.plan
-        r6, rmat = data[0].float(), data[1].float()
+        r6, rmat = data[0].to(self.dtype), data[1].to(self.dtype)
+        eps_list = [None if e is None else e.to(self.dtype) for e in eps_list]
         b, T, _ = r6.shape
         nj = hp["n_joints"]
         gt_pos = fk_positions(rmat.reshape(b * T, nj, 3, 3), self.parents, self.offsets).detach().reshape(b, T, -1)
@@ -483,14 +489,15 @@ class OracleVAE:
         hp, p = self.hp, self.plan
         b, T = target_rmat.shape[0], target_rmat.shape[1]
         nj = hp["n_joints"]
-        z_list = [z_shallow] + [torch.zeros(b, p.edge_num[i + 1], p.lat_dim[i]) for i in range(1, p.L - 1)] + [z_deep]
+        z_list = [z_shallow] + [torch.zeros(b, p.edge_num[i + 1], p.lat_dim[i], dtype=self.dtype)
+                                for i in range(1, p.L - 1)] + [z_deep]
         c6, R, pos, dec_out = self.decode(z_list)
-        gtR = target_rmat.float()
+        gtR = target_rmat.to(self.dtype)
         g6 = torch.stack((gtR[..., 0], gtR[..., 1]), dim=-2).reshape(b, T, nj, 6)          # :1279-1280
         gt_pos = fk_positions(gtR.reshape(b * T, nj, 3, 3), self.parents, self.offsets).reshape(b, T, nj, 3)
 
         def masked(pred, gt):                                                               # :717-735
-            m = mask.float().reshape(tuple(mask.shape) + (1,) * (pred.dim() - 3))
+            m = mask.to(self.dtype).reshape(tuple(mask.shape) + (1,) * (pred.dim() - 3))
             return (((pred - gt) ** 2) * m).mean()
 
         l6, lr, lp = masked(c6, g6), masked(R, gtR), masked(pos, gt_pos)
@@ -578,15 +585,18 @@ class OracleTrajectory:
     std_root: the three de-standardisation factors `std_vals[0, 576:579]` (:283-290; the mean cancels in the loss).
     """
 
-    def __init__(self, hp, params, mean_root, std_root, parents=SMPL24_PARENTS):
+    def __init__(self, hp, params, mean_root, std_root, parents=SMPL24_PARENTS, dtype=torch.float32):
+        """dtype: float32 = the reference's arithmetic; float64 = the same graph in double (see OracleVAE)."""
         self.hp = hp
+        self.dtype = dtype
         self.plan = p = TrajPlan(hp, parents)
-        self.masks = traj_masks(p)
-        self.pool_w = [pool_matrix(p.pooling[i], p.edge_num[i], p.enc_cout[i] // p.edge_num[i]) for i in range(p.L)]
-        self.mean_root = torch.as_tensor(mean_root, dtype=torch.float32).reshape(1, 1, 3)
-        self.std_root = torch.as_tensor(std_root, dtype=torch.float32).reshape(1, 1, 3)
+        self.masks = {k: v.to(dtype) for k, v in traj_masks(p).items()}
+        self.pool_w = [pool_matrix(p.pooling[i], p.edge_num[i], p.enc_cout[i] // p.edge_num[i]).to(dtype)
+                       for i in range(p.L)]
+        self.mean_root = torch.as_tensor(mean_root, dtype=torch.float32).reshape(1, 1, 3).to(dtype)
+        self.std_root = torch.as_tensor(std_root, dtype=torch.float32).reshape(1, 1, 3).to(dtype)
         shapes = traj_param_shapes(p)
-        self.params = {k: v.detach().clone().float().requires_grad_(True) for k, v in params.items() if k in shapes}
+        self.params = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in params.items() if k in shapes}
 
     def trainable(self):
         return [(n, self.params[n]) for n in traj_param_shapes(self.plan)]
@@ -614,7 +624,7 @@ class OracleTrajectory:
     def min_abs_preactivation(self, joint_pos):
         """Smallest |LeakyReLU input| over all layers (tests skip draws where it is within fp32 rounding of 0)."""
         p, P = self.plan, self.params
-        x = joint_pos.float().transpose(1, 2)
+        x = joint_pos.to(self.dtype).transpose(1, 2)
         m = float("inf")
         with torch.no_grad():
             for i in range(p.L):
@@ -629,7 +639,7 @@ class OracleTrajectory:
         """:220-235 — (B,T,72) normalised joint positions -> (B,T,3) normalised root velocity."""
         p = self.plan
         b, T, _ = joint_pos.shape
-        latent = self.encode(joint_pos.float().transpose(1, 2), branch)
+        latent = self.encode(joint_pos.to(self.dtype).transpose(1, 2), branch)
         k = latent.shape[1] // p.d_model
         feat = latent.reshape(b, k, p.d_model, T).transpose(2, 3).transpose(1, 2).reshape(b, T, -1)
         return F.linear(feat, self.params["fc_mapping.weight"], self.params["fc_mapping.bias"])
@@ -648,7 +658,7 @@ class OracleTrajectory:
     def train_forward(self, data, backward=True, branch=None):
         """:196-265.  data = the 7-tuple of the loader; uses rot_pos [2], joint_pos [3], root_v [6]."""
         hp = self.hp
-        rot_pos, joint_pos, root_v = data[2].float(), data[3].float(), data[6].float()
+        rot_pos, joint_pos, root_v = data[2].to(self.dtype), data[3].to(self.dtype), data[6].to(self.dtype)
         b, T, _ = joint_pos.shape
         out_v = self.root_velocity(joint_pos, branch)
         l_v = ((out_v - root_v) ** 2).mean()

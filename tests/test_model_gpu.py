@@ -89,8 +89,18 @@ def test_forward_backward_vs_reference_golden(dev, tag, phase):
             assert rel_err(gr, g[pre + "|full"]) < TOL, name
         else:
             # sampled entries of the big conv gradients, relative to the tensor's largest sampled magnitude
-            assert rel_err(gr[g[pre + "|idx"]], g[pre + "|val"]) < 5 * TOL, name
+            assert rel_err(gr[g[pre + "|idx"]], g[pre + "|val"]) < TOL, name
     assert none == meta[phase + "_none_grad"]
+    # ... and EVERY entry of every gradient against the float64 evaluation of the oracle (the reference's fp32 samples
+    # above are themselves 1e-5-class approximations of it: tests/test_oracle_golden.py pins the fp32 oracle to them)
+    o64 = O.OracleVAE(cfg, seeded, offsets=offsets(), dtype=torch.float64)
+    o64.train_forward(golden_batch(g), it, golden_eps(g))
+    mine = dict(model.named_parameters())
+    for name, p64 in o64.trainable():
+        if p64.grad is None:
+            assert mine[name].grad is None, name
+            continue
+        assert rel_err(mine[name].grad.cpu().numpy(), p64.grad.numpy()) < TOL, name
     # masked-out conv weight gradients are exactly zero (reference: grad of weight*mask)
     om = O.oracle_masks(plan)
     for k, m in om.items():
