@@ -1,38 +1,83 @@
 """hipGraph replay of the training step (torch.cuda.CUDAGraph = hipGraph on ROCm).
 
 The fused engine issues ~170 short kernel launches per step; captured once, a step becomes one graph launch plus
-one 32-byte device->host copy of the loss scalars.  Under DDP the step is captured as two graphs (forward+backward,
-optimiser) with the RCCL all-reduce of the flat gradient bucket launched eagerly between them.
+one 32-byte device->host copy of the loss scalars.  Under DDP the step is captured as three or four graphs
+([forward + decoder backward] | [encoder backward, coarse | fine] | [optimiser]) with the RCCL all-reduces of the
+gradient bucket's slices launched eagerly between them (asynchronous for all but the last slice).
 """
 import torch
 
 from . import ddp
 
-# Captured graphs are never destroyed.  Destroying a hipGraph that was captured across the engine's side streams and then
-# running eager multi-stream work corrupts the host heap inside the HIP runtime of this ROCm release: glibc aborts in
-# hipDeviceSynchronize ("corrupted size vs. prev_size"; "free(): invalid pointer" under MALLOC_CHECK_=3).  Found with
-# tools/tune_in_situ.py (re-captures the step per candidate): reproducible within 3 re-captures on the TrajectoryModel, gone
-# with HMVAE_OVERLAP=0 (single stream) and gone when the old graphs are kept alive; persistent instead of temporary events
-# did not change it.  A training run re-captures once (phase switch), a refinement loop captures two graphs per window
-# batch: they are parked here (host memory: a few hundred KB each).
+# Graph lifetime.  On the HIP runtime that the torch 2.10+rocm7.0 wheel bundles (libamdhip64 7.0.2, the copy every Python
+# process here runs on) destroying a hipGraphExec that was captured across several streams and launching / synchronising
+# afterwards crashes the process sporadically INSIDE the runtime: SIGSEGV in hip::Graph::UpdateStreams (from hipGraphLaunch)
+# or in amd::Event::processCallbacks (the runtime's signal-handler thread), "corrupted size vs. prev_size" /
+# "free(): invalid pointer" from glibc.  tools/repro/graph_destroy_torch.py shows it with NO code of this repository
+# (torch streams, events and torch.cuda.graph only: 5 crashes in 22 runs of 100 capture / destroy rounds); the same
+# program on the image's ROCm 7.2.0 runtime (LD_PRELOAD=/opt/rocm/lib/libamdhip64.so.7) ran 12 of 12 clean, and with the
+# graphs kept alive 7 of 7 clean on the bundled runtime; the pure-HIP program beside it (graph_destroy_repro.hip) does not
+# trigger it on either runtime, so the trigger involves something torch's capture adds.  Joining only the side streams a
+# step forked (engine._join) or pre-creating the events changes nothing.  Rounds and logs: tools/repro/README.md.
+# So on a runtime older than 7.2 replaced graphs are PARKED (kept alive until the process ends: a few hundred KB of host
+# memory each; training re-captures once, at the phase switch; the refinement loop reuses its graphs across windows) and
+# on a newer one they are destroyed normally, after a device synchronisation.  HMVAE_GRAPH_PARK=0/1 overrides.
+import os as _os
+import warnings as _warnings
+
 _RETIRED = []
 MAX_RETIRED = 64
+_warned = [False]
 
 
-import os as _os
-PARK = _os.environ.get("HMVAE_GRAPH_PARK", "1") != "0"
+def hip_runtime_version():
+    """hipRuntimeGetVersion() of the libamdhip64 mapped into this process (0 if it cannot be asked)."""
+    import ctypes
+    try:
+        v = ctypes.c_int(0)
+        if ctypes.CDLL("libamdhip64.so.7").hipRuntimeGetVersion(ctypes.byref(v)) == 0:
+            return int(v.value)
+    except OSError:
+        pass
+    return 0
+
+
+def _park_default():
+    env = _os.environ.get("HMVAE_GRAPH_PARK")
+    if env is not None:
+        return env != "0"
+    return hip_runtime_version() < 70200000
+
+
+PARK = None           # decided on first use (the runtime library is mapped by then)
+
+
+def parking():
+    global PARK
+    if PARK is None:
+        PARK = _park_default()
+    return PARK
 
 
 def retire(*graphs):
-    if PARK:
-        _RETIRED.extend(g for g in graphs if g is not None)
-    elif any(g is not None for g in graphs):
+    graphs = [g for g in graphs if g is not None]
+    if not graphs:
+        return
+    if parking():
+        _RETIRED.extend(graphs)
+    else:
         torch.cuda.synchronize()            # nothing of the graph is in flight when its last reference goes
 
 
 def may_capture():
-    """False once MAX_RETIRED graphs are parked: callers that create graphs per work item fall back to eager launches."""
-    return (not PARK) or len(_RETIRED) < MAX_RETIRED
+    """False once MAX_RETIRED graphs are parked: callers that would capture per work item launch eagerly from then on
+    (said once, loudly -- replays slow down with many hundred live graphs and the memory is never returned)."""
+    ok = (not parking()) or len(_RETIRED) < MAX_RETIRED
+    if not ok and not _warned[0]:
+        _warned[0] = True
+        _warnings.warn("hm_vae_amd: %d replaced hipGraphs are parked (HIP runtime %d destroys them unsafely); further "
+                       "per-item captures fall back to eager launches" % (len(_RETIRED), hip_runtime_version()))
+    return ok
 
 
 class GraphedStep:

@@ -96,15 +96,27 @@ def test_c_abi_exports_match_header():
 
 
 def test_retired_graphs_are_parked_not_destroyed():
-    """graph_step.retire keeps replaced graphs alive (destroying a multi-stream hipGraph corrupts the runtime's heap on
-    this ROCm release); callers that capture per work item stop capturing at MAX_RETIRED."""
+    """graph_step.retire keeps replaced graphs alive on HIP runtimes older than 7.2 (the bundled 7.0.2 crashes after a
+    multi-stream hipGraphExec is destroyed: graph_step.py, tools/repro/); callers that capture per work item stop
+    capturing at MAX_RETIRED and say so once.  On a newer runtime nothing is parked."""
+    import warnings
     from hm_vae_amd import graph_step
-    before = list(graph_step._RETIRED)
+    before, park, warned = list(graph_step._RETIRED), graph_step.PARK, graph_step._warned[0]
     try:
+        graph_step.PARK, graph_step._warned[0] = True, False
         a, b = object(), object()
         graph_step.retire(a, None, b)
         assert graph_step._RETIRED[-2:] == [a, b] and graph_step.may_capture()
         graph_step._RETIRED.extend([object()] * graph_step.MAX_RETIRED)
-        assert not graph_step.may_capture()
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            assert not graph_step.may_capture()
+            assert not graph_step.may_capture()
+        assert len(seen) == 1 and "parked" in str(seen[0].message)
+        graph_step.PARK = False                       # a runtime that destroys graphs safely: nothing is kept
+        n = len(graph_step._RETIRED)
+        graph_step.retire(None)
+        assert len(graph_step._RETIRED) == n and graph_step.may_capture()
     finally:
         graph_step._RETIRED[:] = before
+        graph_step.PARK, graph_step._warned[0] = park, warned

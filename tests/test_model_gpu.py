@@ -333,7 +333,8 @@ def test_graph_replay_across_the_phase_switch(dev):
         step = GraphedStep(tr, cfg, batch, 0, use_graph=use_graph, warmup=1)
         losses = [step.run() for _ in range(7)]
         if use_graph:
-            assert step.phase2 and len(graph_step._RETIRED) > parked          # re-captured once, old graphs parked
+            assert step.phase2                                                 # re-captured once at the switch
+            assert (len(graph_step._RETIRED) > parked) == graph_step.parking()  # old graphs parked on the 7.0.x runtime
         head = tr.model.state_dict()["enc.latent_enc_layers.0.weight"].detach().cpu().numpy().copy()
         params = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters() if p.requires_grad]).cpu().numpy()
         outs.append((np.array(losses), params, head))

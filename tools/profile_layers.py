@@ -41,6 +41,18 @@ for name, op in zip(names, convs):
         issued_b = 2.0 * gb.mfma_cost() * sum(len(l) for l in op.bwd.pairs_host) * bp
         line += "| bwd: tune %s groups %3d pos %2d %7.1f us %5.1f TF %5.1f TF issued " % (op.bwd.choose(bp), gb.n_groups, op.bwd.n_pos, t_b, useful/t_b/1e6, issued_b/t_b/1e6)
     t_w = timeit(lambda: op.backward_weight(dy, x, dw, bp, slab)); tot["wg"] += t_w
-    line += "| wgrad: tiles %4d split %2d %7.1f us %5.1f TF" % (op.n_tiles, op.n_split(bp), t_w, useful/t_w/1e6)
+    t_g = timeit(lambda: op.wgrad_gemm(dy, x, bp, slab))
+    issued_w = op.n_tiles * op.wg.mt * 16 * 64 * 2.0 * op.geom["t_dst"] * bp
+    line += "| wgrad: tiles %4d mt %d split %2s mode %d %7.1f us (gemm %6.1f) %5.1f TF eff, gemm alone %5.1f TF issued" % (
+        op.n_tiles, op.wg.mt, op._split_tuned.get(bp), op.wg_mode(bp), t_w, t_g, useful/t_w/1e6, issued_w/t_g/1e6)
     print(line)
+    if os.environ.get("WG_SWEEP"):
+        for md in (0, 1):
+            if md == 1 and not op.lds_eligible():
+                continue
+            for sp in op.split_candidates(bp):
+                op._mode_tuned[bp], op._split_tuned[bp] = md, sp
+                t_g = timeit(lambda: op.wgrad_gemm(dy, x, bp, slab), reps=8)
+                t_w = timeit(lambda: op.backward_weight(dy, x, dw, bp, slab), reps=8)
+                print("      mode %d split %2d: gemm %7.1f us  gemm+reduce %7.1f us  %5.1f TF issued" % (md, sp, t_g, t_w, issued_w/t_g/1e6))
 print("totals us:", tot, "sum", sum(tot.values()))

@@ -19,14 +19,16 @@ GDB = ["/opt/rocm/bin/rocgdb", "-batch", "-ex", "set pagination off", "-ex", "ru
 REPRO = os.path.join(ROOT, "tools", "repro", "graph_destroy_repro")
 TORCH = [PY, os.path.join(ROOT, "tools", "repro", "graph_destroy_torch.py")]
 CHECK = {"MALLOC_CHECK_": "3", "TUNE_VERBOSE": "1"}
-EXPERIMENTS = [
-    ("hip_mode0", [REPRO, "0", "200"], CHECK, 300),
-    ("hip_mode1", [REPRO, "1", "200"], CHECK, 300),
-    ("torch_mode0", TORCH + ["0", "100"], CHECK, 300),
-    ("torch_mode1", TORCH + ["1", "100"], CHECK, 300),
-    ("tuner_destroy_joinall_gdb", GDB + TUNER, dict(CHECK, HMVAE_GRAPH_PARK="0", HMVAE_JOIN_ALL="1"), 900),
-    ("tuner_destroy_joinforked", TUNER, dict(CHECK, HMVAE_GRAPH_PARK="0", HMVAE_JOIN_ALL="0"), 900),
-]
+EXPERIMENTS = []
+TORCH_LIB = os.path.join(os.path.dirname(__import__("torch").__file__), "lib")       # the ROCm 7.0.2 runtime torch bundles
+OLD = dict(CHECK, LD_LIBRARY_PATH=TORCH_LIB)
+NEW = dict(CHECK, LD_PRELOAD="/opt/rocm/lib/libamdhip64.so.7")                         # the image's ROCm 7.2.0 runtime
+for rep in range(6):
+    for ja, rot in ((0, 0), (0, 1)):
+        EXPERIMENTS.append(("hip_rt702_j%d_r%d_rep%d" % (ja, rot, rep), [REPRO, str(ja), str(rot), "1", "1", "1", "300"], OLD, 120))
+for rep in range(6):
+    EXPERIMENTS.append(("torch_rt720_j0_r1_rep%d" % rep, TORCH + ["0", "1", "0", "0", "100"], NEW, 300))
+    EXPERIMENTS.append(("torch_rt720_j0_r0_rep%d" % rep, TORCH + ["0", "0", "0", "0", "100"], NEW, 300))
 
 
 def main():
