@@ -14,7 +14,7 @@ from . import ddp
 # afterwards crashes the process sporadically INSIDE the runtime: SIGSEGV in hip::Graph::UpdateStreams (from hipGraphLaunch)
 # or in amd::Event::processCallbacks (the runtime's signal-handler thread), "corrupted size vs. prev_size" /
 # "free(): invalid pointer" from glibc.  tools/repro/graph_destroy_torch.py shows it with NO code of this repository
-# (torch streams, events and torch.cuda.graph only: 5 crashes in 22 runs of 100 capture / destroy rounds); the same
+# (torch streams, events and torch.cuda.graph only: 5 crashes in 17 runs of 100 capture / destroy rounds); the same
 # program on the image's ROCm 7.2.0 runtime (LD_PRELOAD=/opt/rocm/lib/libamdhip64.so.7) ran 12 of 12 clean, and with the
 # graphs kept alive 7 of 7 clean on the bundled runtime; the pure-HIP program beside it (graph_destroy_repro.hip) does not
 # trigger it on either runtime, so the trigger involves something torch's capture adds.  Joining only the side streams a
