@@ -689,34 +689,30 @@ extern "C" int hmvae_motion_batch(const float* frames, int64_t n_rows, const hmv
 
 // ---------------- exact three-way bf16 split (operand planes of the bf16x3 weight-gradient GEMM) ----------------
 // p0 = top 16 bits of x; r = x - p0 (exact); p1 = top 16 bits of r; p2 = top 16 bits of r - p1 (exact: <= 8 bits left)
+typedef __attribute__((ext_vector_type(2))) __bf16 split_bf16x2;
+typedef float split_f32x2 __attribute__((ext_vector_type(2)));
+
+// x = p0 + p1 + p2 exactly, round-to-nearest-even at every level (v_cvt_pk_bf16_f32): |p1| <= 2^-9 |x|, |p2| <= 2^-17 |x|;
+// each remainder is exactly representable, and the last one has at most 8 significant bits, so nothing is lost.
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ x, uint16_t* __restrict__ planes,
                                                            long long n8, long long plane_stride) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;
     const float4 a = ((const float4*)x)[2 * i], b = ((const float4*)x)[2 * i + 1];
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    unsigned h[8], m[8], l[8];
+    unsigned h[4], m[4], l[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const unsigned hb = __float_as_uint(v[k]) & 0xffff0000u;
-        const float r = v[k] - __uint_as_float(hb);
-        const unsigned mb = __float_as_uint(r) & 0xffff0000u;
-        const float r2 = r - __uint_as_float(mb);
-        h[k] = hb;
-        m[k] = mb;
-        l[k] = __float_as_uint(r2) & 0xffff0000u;
+    for (int k = 0; k < 4; ++k) {
+        const split_f32x2 p = {v[2 * k], v[2 * k + 1]};
+        h[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(p, split_bf16x2));
+        const split_f32x2 r = {p[0] - __uint_as_float(h[k] << 16), p[1] - __uint_as_float(h[k] & 0xffff0000u)};
+        m[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, split_bf16x2));
+        const split_f32x2 q = {r[0] - __uint_as_float(m[k] << 16), r[1] - __uint_as_float(m[k] & 0xffff0000u)};
+        l[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(q, split_bf16x2));
     }
-    auto pack = [](const unsigned* w) {
-        uint4 o;
-        o.x = (w[0] >> 16) | w[1];
-        o.y = (w[2] >> 16) | w[3];
-        o.z = (w[4] >> 16) | w[5];
-        o.w = (w[6] >> 16) | w[7];
-        return o;
-    };
-    *(uint4*)(planes + 8 * i) = pack(h);
-    *(uint4*)(planes + plane_stride + 8 * i) = pack(m);
-    *(uint4*)(planes + 2 * plane_stride + 8 * i) = pack(l);
+    *(uint4*)(planes + 8 * i) = make_uint4(h[0], h[1], h[2], h[3]);
+    *(uint4*)(planes + plane_stride + 8 * i) = make_uint4(m[0], m[1], m[2], m[3]);
+    *(uint4*)(planes + 2 * plane_stride + 8 * i) = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
 extern "C" int hmvae_split_bf16x3(const float* x, uint16_t* planes, int64_t n, int64_t plane_stride, hmvae_stream_t stream) {

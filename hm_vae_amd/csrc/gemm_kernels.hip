@@ -482,6 +482,7 @@ static void launch_wgrad(const hmvae_wgrad_desc* d, dim3 grid, hipStream_t s) {
 }
 
 int hmvae_wgrad_lds_launch(const hmvae_wgrad_desc* d, unsigned grid, hipStream_t s);      // wgrad_lds.hip
+int hmvae_wgrad_bf3_launch(const hmvae_wgrad_desc* d, unsigned grid, hipStream_t s);      // wgrad_bf3.hip
 
 extern "C" int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream) {
     if (!desc || !desc->dz || !desc->x || !desc->slab) return HMVAE_ERR_ARG;
@@ -502,6 +503,10 @@ extern "C" int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t str
     if (desc->mode == 1) {
         if (desc->t_dst < 4) return HMVAE_ERR_UNSUPPORTED;
         return hmvae_wgrad_lds_launch(desc, grid.x, s);
+    }
+    if (desc->mode == 2) {
+        if (desc->t_dst < 4) return HMVAE_ERR_UNSUPPORTED;
+        return hmvae_wgrad_bf3_launch(desc, grid.x, s);
     }
     if (desc->mode != 0) return HMVAE_ERR_ARG;
     switch (desc->mt) {

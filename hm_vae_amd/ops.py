@@ -41,6 +41,10 @@ WGRAD_BF16X3 = _os.environ.get("HMVAE_WGRAD_BF16X3", "0")
 # with the unbiased alone-timed choice; 144-146 k with the in-situ choices of TUNE_DEFAULTS).  Where it loses by more than
 # the bias (the trajectory model's 31-tap layers: 87 vs 95 k seq/s when forced) the direct kernel stays.
 WGRAD_LDS = _os.environ.get("HMVAE_WGRAD_LDS", "auto")
+# mode 2 of the same descriptor: LDS-staged like mode 1, every element split in-kernel into three bf16 planes and the six
+# significant cross terms run on the bf16 matrix pipe (csrc/wgrad_bf3.hip): fp32-grade sums at 3/8 of the fp32 MFMA issue
+# cycles.  A candidate of the autotuner unless HMVAE_WGRAD_BF3=0; HMVAE_WGRAD_LDS=2 forces it wherever it applies.
+WGRAD_BF3 = _os.environ.get("HMVAE_WGRAD_BF3", "1") != "0"
 LDS_BIAS = float(_os.environ.get("HMVAE_LDS_BIAS", "0.83"))
 # optional JSON file that persists the autotuner's choices between processes (profiling runs reuse it so the trace
 # holds only the launches of the timed steps)
@@ -598,17 +602,40 @@ class MaskedGemm:
         ge = self.geom
         return (not self.wg_transposed) and self.kt >= 2 and ge["t_dst"] >= 4
 
+    def bf3_eligible(self):
+        """Mirror of bf3_geometry (csrc/wgrad_bf3.hip): hmvae_wgrad_desc.mode = 2 supports this problem."""
+        ge = self.geom
+        mt = self.wg.mt
+        if not self.lds_eligible() or mt > 4:
+            return False
+        nch_max = 63 // self.kt + 2
+        W = 3 * ge["stride"] + self.kt
+        WP = self.kt
+        while WP < W:
+            WP += 8
+        WT = (ge["t_dst"] - 1) * ge["stride"] + self.kt
+        if (nch_max * W + 31) // 32 > 8:
+            return False
+        lds = (nch_max * WT * 4 + 15) // 16 * 16 + 3 * (mt * 16 * 4 + nch_max * WP + 1) * 64
+        return max(lds, 4 * mt * 16 * 64 * 4) <= 80 * 1024
+
     def wg_mode(self, bp):
         if not self.lds_eligible() or self.use_bf(bp):
             return 0
         if WGRAD_LDS in ("0", "1"):
             return int(WGRAD_LDS)
-        return int(self._mode_tuned.get(bp, 0))
+        if WGRAD_LDS == "2":
+            return 2 if self.bf3_eligible() else 0
+        md = int(self._mode_tuned.get(bp, 0))
+        return md if (md < 2 or (WGRAD_BF3 and self.bf3_eligible())) else 0
 
     def use_bf(self, bp):
         if WGRAD_BF16X3 in ("0", "1"):
             return WGRAD_BF16X3 == "1"
         return bool(self._bf_tuned.get(bp, False))
+
+    def desc_mode(self, bp):
+        return self.wg_mode(bp)
 
     def _planes(self, role, t):
         """The three bf16 planes of operand tensor `t` (split on the current stream into this op's scratch)."""
@@ -616,9 +643,10 @@ class MaskedGemm:
         key = (role, n)
         buf = self._plane_buf.get(key)
         if buf is None:
-            buf = self._plane_buf[key] = torch.empty(3 * n, dtype=torch.int16, device=t.device)
-        _lib.check(_lib.load().hmvae_split_bf16x3(_lib.ptr(t), buf.data_ptr(), n, n, _lib.stream()), "split_bf16x3")
-        return buf, n
+            # every plane ends with 64 zero elements: the zero row of hmvae_wgrad_desc.mode 2 (never written by the split)
+            buf = self._plane_buf[key] = torch.zeros(3 * (n + 64), dtype=torch.int16, device=t.device)
+        _lib.check(_lib.load().hmvae_split_bf16x3(_lib.ptr(t), buf.data_ptr(), n, n + 64, _lib.stream()), "split_bf16x3")
+        return buf, n + 64
 
     def _plane_args(self, dy, x, bp):
         if not self.use_bf(bp):
@@ -640,7 +668,7 @@ class MaskedGemm:
         # resident workgroups per CU by registers (VGPR + AGPR of the unified 512 per SIMD lane): mt 1 / 2 use 128 / 198,
         # mt 3 uses 268 and mt 4 333 -> one wave per SIMD (counted with rocprofv3: 838 of 1024 wave slots busy on average
         # for 1127 one-per-CU workgroups: the fifth round is 40 % empty)
-        per_cu = int(_os.environ.get("HMVAE_WG_PER_CU", "0")) or (2 if (mt <= 2 or self.wg_mode(bp) == 1) else 1)
+        per_cu = int(_os.environ.get("HMVAE_WG_PER_CU", "0")) or (2 if (mt <= 2 or self.wg_mode(bp) >= 1) else 1)
         n_workers = max(8, (n_cu * per_cu) // 8 * 8)
         segs, wseg, _, _ = P.build_stream_schedule([kc] * n_tiles, [1] * n_tiles, n_workers, min_steps=2)
         items = np.zeros((max(len(segs), 1), 4), dtype=np.int32)
@@ -666,7 +694,7 @@ class MaskedGemm:
         return max(max(self.split_candidates(bp)) * per, parts_p * mt * 16 * 64)
 
     def wg_tune_key(self, bp):
-        return "wg4_t%d_m%d_k%d_c%d_tr%d_b%d" % (self.n_tiles_t if self.wg_transposed else self.n_tiles, self.wg.mt, self.kt,
+        return "wg5_t%d_m%d_k%d_c%d_tr%d_b%d" % (self.n_tiles_t if self.wg_transposed else self.n_tiles, self.wg.mt, self.kt,
                                                  self._k_chunks(bp), int(self.wg_transposed), bp)
 
     def autotune_split(self, dy, x, dw, bp, slab):
@@ -692,6 +720,8 @@ class MaskedGemm:
             modes = [(True, 0)]
         if WGRAD_LDS == "auto" and self.lds_eligible() and WGRAD_BF16X3 != "1":
             modes.append((False, 1))
+            if WGRAD_BF3 and self.bf3_eligible():
+                modes.append((False, 2))
         for bf, md in modes:
             self._bf_tuned[bp] = bf
             self._mode_tuned[bp] = md
@@ -763,9 +793,9 @@ class MaskedGemm:
 
     def _wg_items(self, bp):
         if not self.persistent(bp):
-            return (None, None, 0, self.wg_mode(bp))
+            return (None, None, 0, self.desc_mode(bp))
         sc = self.wg_schedule(bp)
-        return (_lib.ptr(sc["items"]), _lib.ptr(sc["worker_items"]), sc["n_workers"], self.wg_mode(bp))
+        return (_lib.ptr(sc["items"]), _lib.ptr(sc["worker_items"]), sc["n_workers"], self.desc_mode(bp))
 
     def _wg_parts(self, bp):
         if not self.persistent(bp):

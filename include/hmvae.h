@@ -187,7 +187,11 @@ typedef struct {
     int32_t mode;            /* 0: operands straight from global memory in MFMA layout.  1: staged through LDS per 4 positions
                                 (gradient rows as whole lines, the activation operand as a window of rows per channel); not
                                 for transposed / bf16-plane / single-tap problems or fewer than 4 positions
-                                (HMVAE_ERR_UNSUPPORTED) */
+                                (HMVAE_ERR_UNSUPPORTED).  2: staged through LDS like mode 1, but every element is split on
+                                the way into THREE bf16 planes (x = p0 + p1 + p2 exactly, round to nearest) and the products
+                                run on the bf16 matrix pipe as the six cross terms of weight >= 2^-16 -- fp32-grade results
+                                (everything above 2^-24 of a product is kept, accumulation in fp32) at 3/8 of the fp32
+                                instruction's issue cycles; same restrictions as mode 1 */
     /* Optional: both operands as three bf16 planes each (hmvae_split_bf16x3: value = plane0 + plane1 + plane2 exactly),
      * plane p of element i at planes[p * plane_stride + i], same element indexing as dz / x.  When dz_planes is given the
      * products run on the bf16 matrix pipe as six cross terms per fp32 product (everything above 2^-23 of it), fp32
@@ -199,8 +203,10 @@ typedef struct {
 
 int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream);
 
-/* x[i] -> planes[p * plane_stride + i], p = 0..2: the exact three-way bf16 split of an fp32 tensor (truncations of the
- * running remainder: 8 + 8 + 8 significand bits), n a multiple of 8. */
+/* x[i] -> planes[p * plane_stride + i], p = 0..2: the exact three-way bf16 split of an fp32 tensor (each plane is the
+ * round-to-nearest bf16 of the running remainder: x = p0 + p1 + p2 exactly), n a multiple of 8.  Elements n .. plane_stride
+ * of a plane are not touched: hmvae_wgrad_desc.mode 2 reads the last 32 of them as its zero row (plane_stride >= n + 32,
+ * zero-filled by the caller once). */
 int hmvae_split_bf16x3(const float* x, uint16_t* planes, int64_t n, int64_t plane_stride, hmvae_stream_t stream);
 
 /* dense[row_out[g,r]*row_stride + chan_id[c]*chan_stride + tap] (+)= sum_s slab[s][tile][r][col] */

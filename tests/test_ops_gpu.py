@@ -526,8 +526,10 @@ def test_wgrad_bf16x3_planes_match_fp32_path(dev, monkeypatch):
     dict(kt=31, stride=1, pad=15, mode="reflect", t_in=40, B=8),         # the trajectory model's taps
 ])
 def test_wgrad_lds_staged_kernel_matches_direct(dev, monkeypatch, cfg):
-    """hmvae_wgrad_desc.mode = 1 (operands staged through LDS, activation window per channel) against the direct kernel
-    for every split the autotuner may pick, incl. the persistent schedule: same sums, different summation order."""
+    """hmvae_wgrad_desc.mode = 1 (operands staged through LDS, activation window per channel) and mode = 2 (the same
+    staging with every element split into three bf16 planes, six cross terms on the bf16 matrix pipe) against the direct
+    fp32 kernel for every split the autotuner may pick, incl. the persistent schedule: same sums, different summation
+    order -- and all three against a float64 evaluation of the convolution's weight gradient (skeleton.py:95-105)."""
     from hm_vae_amd import ops
     neigh = [[0, 1], [0, 1, 2], [1, 2, 3], [2, 3, 4], [3, 4]]
     cin, cout = 5 * 6, 5 * 12
@@ -544,15 +546,30 @@ def test_wgrad_lds_staged_kernel_matches_direct(dev, monkeypatch, cfg):
     dy[:, :B] = torch.randn(cout * t_out, B, device=dev)
     slab = torch.empty(op.slab_floats(bp), device=dev)
     monkeypatch.setattr(ops, "AUTOTUNE", False)
+    # float64 yardstick: dW = d/dW sum(dy * conv1d(pad(x), W * mask))
+    xb = x[:, :B].reshape(cin, cfg["t_in"], B).permute(2, 0, 1).double().cpu()
+    gb = dy[:, :B].reshape(cout, t_out, B).permute(2, 0, 1).double().cpu()
+    wt = torch.zeros(cout, cin, cfg["kt"], dtype=torch.float64, requires_grad=True)
+    mask = O.conv_mask(neigh, cin, cout, cfg["kt"]).double()
+    (O.skel_conv(xb, wt, mask, None, cfg["stride"], cfg["pad"], O._pad_mode(cfg["mode"])) * gb).sum().backward()
+    exact = wt.grad.numpy()
+    assert op.bf3_eligible()
     ref = None
-    for mode in ("0", "1"):
+    worst = {}
+    for mode in ("0", "1", "2"):
         monkeypatch.setattr(ops, "WGRAD_LDS", mode)
         for split in op.split_candidates(bp) + (["p"] if op._k_chunks(bp) >= 8 else []):
             op._split_tuned[bp] = split
             dw = torch.zeros(cout, cin, cfg["kt"], device=dev)
             op.backward_weight(dy, x, dw, bp, slab)
+            assert op.wg_mode(bp) == int(mode)
             if ref is None:
                 ref = dw
                 assert float(ref.abs().max()) > 0
             else:
                 assert rel_err(dw.cpu().numpy(), ref.cpu().numpy()) < 2e-6, (mode, split)
+            worst[mode] = max(worst.get(mode, 0.0), rel_err(dw.cpu().numpy(), exact))
+    # fp32-grade: the three-plane kernel is as close to float64 as the fp32 kernels (it rounds once per 32-term dot
+    # product instead of once per term)
+    assert max(worst.values()) < 2e-6, worst
+    assert worst["2"] <= 1.5 * worst["0"] + 1e-7, worst

@@ -27,7 +27,12 @@ tot = {"fwd": 0, "bwd": 0, "wg": 0}
 print("B=%d bp=%d" % (B, bp))
 for name, op in zip(names, convs):
     cout, cin, kt = op.w_shape
-    x = torch.randn(cin * op.t_in + 400000, bp, device=dev); y = torch.empty(cout * op.t_out + 400000, bp, device=dev)
+    # exact-size operands (mode 3 splits the whole tensor per call); the gather sides may address rows of a wider buffer
+    rows_x = max(cin * op.t_in, int(op.wg_chan_rows.max().item()) + op.geom["t_src"] * op.x_ts + 8)
+    rows_y = max(cout * op.t_out, int(op.dz_rows.max().item()) + op.geom["t_dst"] * op.y_ts + 8)
+    if op.folded:
+        rows_x, rows_y = rows_x + 400000, rows_y + 400000
+    x = torch.randn(rows_x, bp, device=dev); y = torch.empty(rows_y, bp, device=dev)
     dy = torch.randn(y.shape[0], bp, device=dev); dx = torch.empty_like(x); dw = torch.zeros(cout, cin, kt, device=dev)
     slab = torch.empty(op.slab_floats(bp), device=dev)
     useful = 2.0 * op.useful_macs_per_col * bp
@@ -47,11 +52,21 @@ for name, op in zip(names, convs):
         op.n_tiles, op.wg.mt, op._split_tuned.get(bp), op.wg_mode(bp), t_w, t_g, useful/t_w/1e6, issued_w/t_g/1e6)
     print(line)
     if os.environ.get("WG_SWEEP"):
-        for md in (0, 1):
-            if md == 1 and not op.lds_eligible():
+        for md in (0, 1, 2):
+            if (md == 1 and not op.lds_eligible()) or (md >= 2 and not op.bf3_eligible()):
                 continue
             for sp in op.split_candidates(bp):
                 op._mode_tuned[bp], op._split_tuned[bp] = md, sp
+                if md == 3:      # the kernel alone on planes made once; the split pass is timed on its own below
+                    xw, dyw = x[:rows_x - 400000] if op.folded else x, dy[:rows_y - 400000] if op.folded else dy
+                    args = op._plane_args(dyw, xw, bp)
+                    real = op._plane_args
+                    op._plane_args = lambda *a, _v=args: _v
+                    t_k = timeit(lambda: op.wgrad_gemm(dy, x, bp, slab), reps=8)
+                    op._plane_args = real
+                    t_s = timeit(lambda: real(dyw, xw, bp), reps=8)
+                    print("      mode 3 split %2d: kernel %7.1f us  + plane split %6.1f us   %5.1f TF issued (kernel)" % (sp, t_k, t_s, issued_w/t_k/1e6))
+                    continue
                 t_g = timeit(lambda: op.wgrad_gemm(dy, x, bp, slab), reps=8)
                 t_w = timeit(lambda: op.backward_weight(dy, x, dw, bp, slab), reps=8)
                 print("      mode %d split %2d: gemm %7.1f us  gemm+reduce %7.1f us  %5.1f TF issued" % (md, sp, t_g, t_w, issued_w/t_g/1e6))
