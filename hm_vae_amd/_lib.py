@@ -53,7 +53,8 @@ class WgradDesc(C.Structure):
                 ("mt", _i32), ("kt", _i32), ("n_split", _i32), ("t_dst", _i32), ("t_src", _i32), ("stride", _i32),
                 ("pad", _i32), ("pad_mode", _i32), ("bp", _i32), ("dz_ts", _i32), ("x_ts", _i32), ("transposed", _i32),
                 ("items", _ptr), ("worker_items", _ptr), ("n_workers", _i32), ("mode", _i32),
-                ("dz_planes", _ptr), ("x_planes", _ptr), ("dz_plane_stride", _i64), ("x_plane_stride", _i64)]
+                ("dz_planes", _ptr), ("x_planes", _ptr), ("dz_plane_stride", _i64), ("x_plane_stride", _i64),
+                ("fused_reduce", _ptr)]
 
 
 class WreduceDesc(C.Structure):

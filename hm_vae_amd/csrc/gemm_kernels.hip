@@ -504,6 +504,7 @@ extern "C" int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t str
         if (desc->t_dst < 4) return HMVAE_ERR_UNSUPPORTED;
         return hmvae_wgrad_lds_launch(desc, grid.x, s);
     }
+    if (desc->fused_reduce && desc->mode != 2) return HMVAE_ERR_UNSUPPORTED;
     if (desc->mode == 2) {
         if (desc->t_dst < 4) return HMVAE_ERR_UNSUPPORTED;
         return hmvae_wgrad_bf3_launch(desc, grid.x, s);

@@ -37,6 +37,7 @@
 // per MFMA.
 #include <hip/hip_runtime.h>
 #include "hmvae.h"
+#include "wreduce_inl.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -184,6 +185,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(hmvae_wgrad_desc d, i
         const unsigned dz_tstep = (unsigned)d.dz_ts * (unsigned)bp * 4u;
         const char* __restrict__ dzb = (const char*)d.dz;
         const char* __restrict__ xb = (const char*)d.x;
+        // fused epilogue: this thread's column of the tile (channel, tap, mask pointer) and the ids / mask bytes of its
+        // rows are looked up NOW -- chains of dependent global loads that would otherwise sit exposed at the tile's end
+        WreduceCol wc = {};
+        int e_rid[MT * 4];
+        unsigned e_bits[MT * 4];
+        if (d.fused_reduce != nullptr) {
+            const hmvae_wreduce_desc& rd = *d.fused_reduce;
+            wc = wreduce_col(rd, tile, threadIdx.x & 63);
+#pragma unroll
+            for (int i = 0; i < MT * 4; ++i) {
+                const int row = (threadIdx.x >> 6) + 4 * i;
+                e_rid[i] = rd.row_id[g * (MT * 16) + row];
+                e_bits[i] = wc.live ? wc.okp[row * wc.ok_stride] : 0u;
+            }
+        }
         __syncthreads();                                          // utab visible
 
         f32x4 acc[MT][4];
@@ -281,16 +297,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(hmvae_wgrad_desc d, i
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mine[(mt * 16 + kk * 4 + r) * 64 + nt * 16 + n] = acc[mt][nt][r];
         __syncthreads();
-        const int rl = threadIdx.x >> 4;
-        const int cq = threadIdx.x & 15;
-        float* out = d.slab + part * (MT * 16 * 64);
+        if (d.fused_reduce != nullptr) {
+            // the tile goes straight into the dense gradient: thread = one column x 4 of every 16 rows (as wreduce_kernel,
+            // so a column's (channel, tap) split and mask pointer are computed once)
+            const hmvae_wreduce_desc& rd = *d.fused_reduce;
+            const int col = threadIdx.x & 63, r0 = threadIdx.x >> 6;
 #pragma unroll
-        for (int ps = 0; ps < MT; ++ps) {
-            const int row = ps * 16 + rl;
-            f32x4 sacc = *(const f32x4*)(red + row * 64 + (cq << 2));
+            for (int i = 0; i < MT * 4; ++i) {
+                const int row = r0 + 4 * i;
+                float sacc = red[row * 64 + col];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) sacc += *(const f32x4*)(red + w * (MT * 16 * 64) + row * 64 + (cq << 2));
-            *(f32x4*)(out + row * 64 + (cq << 2)) = sacc;
+                for (int w = 1; w < 4; ++w) sacc += red[w * (MT * 16 * 64) + row * 64 + col];
+                wreduce_store(rd, wc, e_rid[i], e_bits[i], sacc);
+            }
+        } else {
+            const int rl = threadIdx.x >> 4;
+            const int cq = threadIdx.x & 15;
+            float* out = d.slab + part * (MT * 16 * 64);
+#pragma unroll
+            for (int ps = 0; ps < MT; ++ps) {
+                const int row = ps * 16 + rl;
+                f32x4 sacc = *(const f32x4*)(red + row * 64 + (cq << 2));
+#pragma unroll
+                for (int w = 1; w < 4; ++w) sacc += *(const f32x4*)(red + w * (MT * 16 * 64) + row * 64 + (cq << 2));
+                *(f32x4*)(out + row * 64 + (cq << 2)) = sacc;
+            }
         }
         __syncthreads();
     }
@@ -301,6 +332,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(hmvae_wgrad_desc d, i
 // Geometry shared with the host-side eligibility check (ops.py mirrors it): returns the LDS bytes, or 0 if unsupported.
 static size_t bf3_geometry(const hmvae_wgrad_desc* d, int* nch_max, int* W, int* WP, int* WT, int* BPs, int* brows) {
     if (d->transposed || d->dz_planes || d->kt < 2 || d->t_dst < TB || d->mt < 1 || d->mt > 4) return 0;
+    if (d->fused_reduce && (d->n_split != 1 || d->n_workers != 0)) return 0;
     *nch_max = 63 / d->kt + 2;
     *W = (TB - 1) * d->stride + d->kt;
     *WP = d->kt;

@@ -45,6 +45,8 @@ WGRAD_LDS = _os.environ.get("HMVAE_WGRAD_LDS", "auto")
 # significant cross terms run on the bf16 matrix pipe (csrc/wgrad_bf3.hip): fp32-grade sums at 3/8 of the fp32 MFMA issue
 # cycles.  A candidate of the autotuner unless HMVAE_WGRAD_BF3=0; HMVAE_WGRAD_LDS=2 forces it wherever it applies.
 WGRAD_BF3 = _os.environ.get("HMVAE_WGRAD_BF3", "1") != "0"
+# the mode-2 GEMM writes the dense gradient from its own epilogue where the reduction is not split (no slab, no reduce launch)
+FUSE_WREDUCE = _os.environ.get("HMVAE_FUSE_WREDUCE", "1") != "0"
 LDS_BIAS = float(_os.environ.get("HMVAE_LDS_BIAS", "0.83"))
 # optional JSON file that persists the autotuner's choices between processes (profiling runs reuse it so the trace
 # holds only the launches of the timed steps)
@@ -551,6 +553,7 @@ class MaskedGemm:
         self._split_tuned = {}
         self._bf_tuned = {}
         self._mode_tuned = {}
+        self._fused = {}
         self._plane_buf = {}
         ge = self.geom
         if (self.bwd is not None and not self.folded and ge["stride"] == 1 and ge["pad_mode"] == _lib.PAD_REFLECT
@@ -729,7 +732,8 @@ class MaskedGemm:
                 self._split_tuned[bp] = c
 
                 def once():
-                    self.wgrad_gemm(dy, x, bp, slab)             # includes the operand split in bf mode
+                    if self.wgrad_gemm(dy, x, bp, slab, dw=scratch):     # includes the operand split in bf mode
+                        return
                     r = self.reduce_desc(slab, scratch, bp, False)
                     _lib.check(_lib.load().hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce")
                 t = self.fwd._time(once) * (LDS_BIAS if md == 1 else 1.0)
@@ -742,9 +746,25 @@ class MaskedGemm:
 
     def backward_weight(self, dy, x, dw, bp, slab, accumulate=False):
         self.autotune_split(dy, x, dw, bp, slab)
-        self.wgrad_gemm(dy, x, bp, slab)
+        if self.wgrad_gemm(dy, x, bp, slab, dw=dw, accumulate=accumulate):
+            return                                   # the GEMM's epilogue wrote the dense gradient itself
         r = self.reduce_desc(slab, dw, bp, accumulate)
         _lib.check(_lib.load().hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce")
+
+    def fusable(self, bp):
+        """The launch can write the dense gradient from its epilogue (hmvae_wgrad_desc.fused_reduce)."""
+        return FUSE_WREDUCE and self.wg_mode(bp) == 2 and self.n_split(bp) == 1 and not self.persistent(bp)
+
+    def _fused_desc(self, slab, dw, bp, accumulate):
+        """Device copy of the reduce descriptor for (slab, dw): made once per pointer set, outside any stream capture."""
+        key = (slab.data_ptr(), dw.data_ptr(), int(bp), bool(accumulate))
+        t = self._fused.get(key)
+        if t is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.HmvaeError("fused weight-gradient epilogue: descriptor for new buffers during a stream capture")
+            r = self.reduce_desc(slab, dw, bp, accumulate)
+            t = self._fused[key] = torch.frombuffer(bytearray(bytes(r)), dtype=torch.uint8).to(self.device)
+        return t.data_ptr()
 
     def reduce_desc(self, slab, dw, bp, accumulate=False):
         """Descriptor of the slab -> dense-gradient reduction (for hmvae_wgrad_reduce[_multi])."""
@@ -775,10 +795,14 @@ class MaskedGemm:
             return self.n_tiles_t * self.bwd.g.mt * 16 * 64
         return self.n_tiles * self.wg.mt * 16 * 64
 
-    def wgrad_gemm(self, dy, x, bp, slab):
+    def wgrad_gemm(self, dy, x, bp, slab, dw=None, accumulate=False):
+        """The GEMM launch.  With `dw` given and the launch fusable, its epilogue writes the dense gradient and the call
+        returns True (no reduce launch is needed); otherwise the tile sums land in `slab`."""
         if self.wg_transposed:
-            return self._wgrad_gemm_t(dy, x, bp, slab)
+            self._wgrad_gemm_t(dy, x, bp, slab)
+            return False
         lib = _lib.load()
+        fused = self._fused_desc(slab, dw, bp, accumulate) if (dw is not None and self.fusable(bp)) else None
         g = self.wg
         tb = self.wg_tabs
         ns = self.n_split(bp)
@@ -788,8 +812,9 @@ class MaskedGemm:
                            _lib.ptr(self.g_ncols), _lib.ptr(tb["g_choff"]), _lib.ptr(self.wg_chan_rows),
                            _lib.ptr(self.dz_rows), self.n_tiles, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"],
                            ge["stride"], ge["pad"], ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 0, *self._wg_items(bp),
-                           *self._plane_args(dy, x, bp))
+                           *self._plane_args(dy, x, bp), fused)
         _lib.check(lib.hmvae_wgrad_gemm(C.byref(d), _lib.stream()), "wgrad_gemm")
+        return fused is not None
 
     def _wg_items(self, bp):
         if not self.persistent(bp):
@@ -815,7 +840,7 @@ def _mg_wgrad_gemm_t(self, dy, x, bp, slab):
     d = _lib.WgradDesc(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(slab), _lib.ptr(self.tile_g_t), _lib.ptr(self.tile_col0_t),
                        _lib.ptr(self.g_ncols_t), _lib.ptr(b.g_choff), _lib.ptr(b.chan_rows), _lib.ptr(b.dst_rows),
                        self.n_tiles_t, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"], ge["stride"], ge["pad"],
-                       ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 1, *self._wg_items(bp), *self._plane_args(dy, x, bp))
+                       ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 1, *self._wg_items(bp), *self._plane_args(dy, x, bp), None)
     _lib.check(lib.hmvae_wgrad_gemm(C.byref(d), _lib.stream()), "wgrad_gemm(T)")
 
 

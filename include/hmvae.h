@@ -199,6 +199,10 @@ typedef struct {
     const uint16_t* dz_planes;
     const uint16_t* x_planes;
     int64_t dz_plane_stride, x_plane_stride;
+    /* Optional, mode 2 with n_split == 1 and n_workers == 0 only: the reduce descriptor of this weight tensor IN DEVICE
+     * MEMORY.  The GEMM's epilogue then writes every tile straight into the dense gradient (mask, deduplicated children,
+     * accumulate: exactly what hmvae_wgrad_reduce does) -- no slab traffic, no reduce launch.  NULL: write the slab. */
+    const struct hmvae_wreduce_desc_s* fused_reduce;
 } hmvae_wgrad_desc;
 
 int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream);
@@ -210,7 +214,7 @@ int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream);
 int hmvae_split_bf16x3(const float* x, uint16_t* planes, int64_t n, int64_t plane_stride, hmvae_stream_t stream);
 
 /* dense[row_out[g,r]*row_stride + chan_id[c]*chan_stride + tap] (+)= sum_s slab[s][tile][r][col] */
-typedef struct {
+typedef struct hmvae_wreduce_desc_s {
     const float* slab;
     float* dense;
     const int32_t* tile_g;
