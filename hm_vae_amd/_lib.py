@@ -143,7 +143,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_PATH
+    path = os.environ.get("HMVAE_LIB") or _build.LIB_PATH      # HMVAE_LIB: a variant build (kernel A/B experiments)
     if not os.path.exists(path):
         if os.path.exists("/opt/rocm/bin/hipcc") or os.environ.get("HIPCC"):
             _build.build(verbose=False)

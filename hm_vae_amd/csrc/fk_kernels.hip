@@ -5,11 +5,13 @@
 //   fk_layer.py:47-93       ForwardKinematicsLayer (4x4 homogeneous chain, 23 gather+bmm+copy_ steps)
 //   seq_two_hier_sa_vae.py:436-474 _decode tail, :395-397/:430-434 the three MSE losses (+ autograd)
 //
-// One thread owns one frame.  The SMPL-24 kinematic tree is compile-time: the traversal is a template
-// recursion (depth-first), so the global rotation of a joint lives in registers only while its subtree
-// is being visited; nothing 4x4 or (N,24,4,4) is ever materialised.  The backward pass is fused in the
-// same traversal: a node returns S = sum of dP over its subtree and H·R^T, the gradient it hands to its
-// parent's global rotation ("FK backward recursion").
+// The SMPL-24 kinematic tree is compile-time: the traversal is a template recursion (depth-first), so the global
+// rotation of a joint lives in registers only while its subtree is being visited; nothing 4x4 or (N,24,4,4) is ever
+// materialised.  A frame's walk is split BY SUBTREE over the four waves of a workgroup (fk_chain_role, fk_bwd_by_role:
+// legs | left arm | right arm | head + trunk), frame-major tensors are staged through LDS in 32-frame tiles; any other
+// tree (<= 64 joints, parents before children) goes through the table-driven kernels at the end of this file.
+// The backward pass is fused in the same traversal: a node returns S = sum of dP over its subtree and H·R^T, the
+// gradient it hands to its parent's global rotation ("FK backward recursion").
 //   p_j = p_par + G_par·off_j,  G_j = G_par·R_j
 //   H_j = sum_{c child of j} ( H_c·R_c^T + S_c ⊗ off_c ),   dR_j = dR_j(direct) + G_par^T·H_j
 #include <hip/hip_runtime.h>
@@ -487,23 +489,413 @@ struct AosBwd {
     }
 };
 
-template <int RD>
-__global__ __launch_bounds__(256) void fk_bwd_aos_kernel(const float* __restrict__ rot, const float* __restrict__ offs,
-                                                         long long off_stride, long long n,
-                                                         const float* __restrict__ dR_up, const float* __restrict__ dP_up,
-                                                         float* __restrict__ d_rot) {
-    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (f >= n) return;
-    AosBwd<RD> io{rot + f * (NJ * RD), offs + f * off_stride, dR_up ? dR_up + f * (NJ * 9) : nullptr,
-                  dP_up ? dP_up + f * (NJ * 3) : nullptr, d_rot + f * (NJ * RD)};
-    fk_bwd_root(io);
+// Fused forward + backward of the chain split by subtree over the four waves of a workgroup (one role per wave: no
+// divergence), shared by the training tail (SoA operands, decode_tail_loss_kernel) and the frame-major backward below:
+//   wave 1: the legs (subtrees of joints 1 and 2, hanging off the root)
+//   wave 2 / 3: the left / right arm (subtrees of 13 / 14, hanging off joint 9)
+//   wave 0: the head (subtree of 12), then -- after one barrier -- the trunk 9 -> 6 -> 3 -> 0 with the limbs' sums
+// Every wave recomputes the trunk's forward chain it needs (<= 4 lifts + 3 products); a limb hands its parent
+// S = sum of dP over the subtree and H = H_c R_c^T + S (x) off_c through LDS (12 floats per frame).
+// Contains one __syncthreads(): every thread of the workgroup must call it (`live` masks the work, not the call).
+template <int FR, class IO>
+__device__ __forceinline__ void fk_bwd_by_role(int role, int lane, bool live, IO& io, float (*xch)[12][FR]) {
+    auto hand_over = [&](int slot, const V3& S, const M3& H) {
+        xch[slot][0][lane] = S.x;
+        xch[slot][1][lane] = S.y;
+        xch[slot][2][lane] = S.z;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) xch[slot][3 + i][lane] = H.a[i];
+    };
+    auto limb = [&](auto child, const M3& G, V3 P, V3& S, M3& H) {      // add subtree `child` to its parent's (S, H)
+        constexpr int C = decltype(child)::value;
+        V3 Sc;
+        M3 Hc;
+        fk_bwd_node<C>(G, P, io, Sc, Hc);
+        S = S + Sc;
+        add_m(H, Hc);
+        add_outer(H, Sc, io.off(C));
+    };
+    M3 G0, G3, G6, G9;
+    V3 P0, P3, P6, P9;
+    if (live) {
+        // forward along the trunk (role 1 only needs the root)
+        io.rot(0, G0);
+        P0 = io.off(0);
+        if (role != 1) {
+            M3 R;
+            io.rot(3, R);
+            P3 = P0 + mulv(G0, io.off(3));
+            G3 = mul(G0, R);
+            io.rot(6, R);
+            P6 = P3 + mulv(G3, io.off(6));
+            G6 = mul(G3, R);
+            io.rot(9, R);
+            P9 = P6 + mulv(G6, io.off(9));
+            G9 = mul(G6, R);
+        }
+        V3 S = {0.f, 0.f, 0.f};
+        M3 H;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) H.a[i] = 0.f;
+        if (role == 1) {
+            limb(std::integral_constant<int, 1>{}, G0, P0, S, H);
+            limb(std::integral_constant<int, 2>{}, G0, P0, S, H);
+        } else if (role == 2) {
+            limb(std::integral_constant<int, 13>{}, G9, P9, S, H);
+        } else if (role == 3) {
+            limb(std::integral_constant<int, 14>{}, G9, P9, S, H);
+        } else {
+            limb(std::integral_constant<int, 12>{}, G9, P9, S, H);
+        }
+        hand_over(role, S, H);
+    }
+    __syncthreads();
+    if (role == 0 && live) {
+        // trunk, leaves to root: node J with the sums (S, H) over its children
+        auto node = [&](int J, const M3& Gp, const M3& R, V3 P, V3& S, M3& H, bool root) {
+            const V3 gp = io.grad_P(J, P);
+            S = S + gp;
+            M3 dR;
+            io.grad_R(J, R, dR);
+            add_m(dR, root ? H : mul_tn(Gp, H));
+            io.emit(J, dR);
+            return mul_nt(H, R);                       // H R^T: what the parent's H receives (plus S (x) off_J)
+        };
+        auto take = [&](int slot, V3& S, M3& H) {
+            S = S + V3{xch[slot][0][lane], xch[slot][1][lane], xch[slot][2][lane]};
+#pragma unroll
+            for (int i = 0; i < 9; ++i) H.a[i] += xch[slot][3 + i][lane];
+        };
+        V3 S = {0.f, 0.f, 0.f};
+        M3 H, R;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) H.a[i] = 0.f;
+        take(0, S, H);                                 // head, left arm, right arm hang off joint 9
+        take(2, S, H);
+        take(3, S, H);
+        io.rot(9, R);
+        M3 Hu = node(9, G6, R, P9, S, H, false);
+        H = Hu;
+        add_outer(H, S, io.off(9));
+        io.rot(6, R);
+        Hu = node(6, G3, R, P6, S, H, false);
+        H = Hu;
+        add_outer(H, S, io.off(6));
+        io.rot(3, R);
+        Hu = node(3, G0, R, P3, S, H, false);
+        H = Hu;
+        add_outer(H, S, io.off(3));
+        take(1, S, H);                                 // the legs hang off the root
+        io.rot(0, R);
+        node(0, R, R, P0, S, H, true);
+    }
 }
 
-bool is_smpl24(const int32_t* parents, int n_joints) {
-    if (!parents || n_joints != NJ) return false;
-    for (int j = 0; j < NJ; ++j)
-        if (parents[j] != smpl_parent(j)) return false;
-    return true;
+// Backward of ForwardKinematicsLayer (+ the 6D lift) on frame-major tensors.  History of this kernel (262 144 frames,
+// 6D input, 2 304 algorithmic bytes per frame):
+//   1. a thread per frame straight on global memory: every load / store instruction touched 64 different 576-byte frames
+//      and the chain was a 24-joint serial walk that lifted every rotation three times -- 491 us;
+//   2. 32-frame LDS tiles + the subtree split of fk_bwd_by_role, lifts still inside the chain: 565 us -- not the memory
+//      access but the chain's instruction count and its 273 registers (one wave per SIMD) were the limit; the same code
+//      compiled for two waves per SIMD (30 spills) ran 336 us;
+//   3. (this version) three phases over the LDS tile, so that the serial part is 3x3 algebra only:
+//      A  stream the rotations (and dL/dR) in; RD == 6: lift them, three joints per thread, inputs kept in registers;
+//      B  the chain by subtree (fk_bwd_by_role) on the LIFTED rotations; a joint's total dL/dR replaces its dL/dR row;
+//      C  RD == 6: the lift's backward for three joints per thread, in parallel; stream the gradient out.
+//      dL/dp is read from global memory inside the chain (three floats per joint: it does not fit the tile twice over).
+template <bool PF>
+struct LdsBwd {
+    const float* R;        // LDS row of this frame: lifted rotations, J*9
+    const float* offs;     // LDS: J*3 (shared or this frame's)
+    float* dR;             // LDS row J*9: dL/dR from upstream (zeros if absent) in, total dL/dR out
+    const float* dP_up;    // global row J*3 of this frame, or nullptr
+    __device__ __forceinline__ void rot(int j, M3& Rm) const {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rm.a[k] = R[j * 9 + k];
+    }
+    __device__ __forceinline__ V3 off(int j) const { return {offs[j * 3], offs[j * 3 + 1], offs[j * 3 + 2]}; }
+    __device__ __forceinline__ V3 grad_P(int j, V3) const {
+        if (dP_up) return {dP_up[j * 3], dP_up[j * 3 + 1], dP_up[j * 3 + 2]};
+        return {0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void grad_R(int j, const M3&, M3& g) const {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) g.a[k] = dR[j * 9 + k];
+    }
+    __device__ __forceinline__ void emit(int j, const M3& g) const {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dR[j * 9 + k] = g.a[k];
+    }
+};
+
+#ifndef FK_BWD_OCC
+#define FK_BWD_OCC 2
+#endif
+template <int RD, bool PF>
+__global__ __launch_bounds__(256, FK_BWD_OCC) void fk_bwd_aos_kernel(const float* __restrict__ rot, const float* __restrict__ offs,
+                                                         long long n, const float* __restrict__ dR_up,
+                                                         const float* __restrict__ dP_up, float* __restrict__ d_rot) {
+    constexpr int L6 = NJ * 6 + 1, LR = NJ * 9 + 1, LP = NJ * 3 + 1;
+    constexpr int LIFTS = NJ * FK_FRAMES / 256;          // joints per thread in the parallel phases
+    extern __shared__ __attribute__((aligned(16))) float fk_lds[];
+    float* sR = fk_lds;                                  // rotations (RD == 6: first the 6D image, last the 6D gradient)
+    float* sD = sR + FK_FRAMES * LR;                     // dL/dR
+    float* sO = sD + FK_FRAMES * LR;                     // offsets
+    float (*xch)[12][FK_FRAMES] = (float (*)[12][FK_FRAMES])(sO + (PF ? FK_FRAMES * LP : NJ * 3 + 1));
+    const long long f0 = (long long)blockIdx.x * FK_FRAMES;
+    const int nf = n - f0 < FK_FRAMES ? (int)(n - f0) : FK_FRAMES;
+    const int f = threadIdx.x & (FK_FRAMES - 1);
+    float o_sh = 0.f;
+    if constexpr (!PF) {
+        if (threadIdx.x < NJ * 3) o_sh = offs[threadIdx.x];
+    }
+    // ---- A ----
+    float in[RD == 6 ? LIFTS : 1][6];
+    if constexpr (RD == 9) fk_stream_in<NJ * 9>(rot + f0 * (NJ * 9), sR, nf);
+    else fk_stream_in<NJ * 6>(rot + f0 * (NJ * 6), sR, nf);
+    if (dR_up) {
+        fk_stream_in<NJ * 9>(dR_up + f0 * (NJ * 9), sD, nf);
+    } else {
+        for (int i = threadIdx.x; i < FK_FRAMES * LR; i += 256) sD[i] = 0.f;
+    }
+    if constexpr (PF) fk_stream_in<NJ * 3>(offs + f0 * (NJ * 3), sO, nf);
+    else if (threadIdx.x < NJ * 3) sO[threadIdx.x] = o_sh;
+    if constexpr (RD == 6) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < LIFTS; ++i) {
+            const int j = (threadIdx.x / FK_FRAMES) + i * (256 / FK_FRAMES);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) in[i][k] = sR[f * L6 + j * 6 + k];
+        }
+        __syncthreads();
+        if (f < nf) {
+#pragma unroll
+            for (int i = 0; i < LIFTS; ++i) {
+                const int j = (threadIdx.x / FK_FRAMES) + i * (256 / FK_FRAMES);
+                M3 Rm;
+                lift6d(in[i], Rm);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) sR[f * LR + j * 9 + k] = Rm.a[k];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- B ----
+    {
+        const int lane = threadIdx.x & 63;
+        const bool live = lane < nf;
+        const int fl = live ? lane : 0;
+        LdsBwd<PF> io{sR + fl * LR, PF ? sO + fl * LP : sO, sD + fl * LR, dP_up ? dP_up + (f0 + fl) * (NJ * 3) : nullptr};
+        fk_bwd_by_role<FK_FRAMES>(threadIdx.x >> 6, fl, live, io, xch);
+    }
+    __syncthreads();
+    // ---- C ----
+    if constexpr (RD == 6) {
+        float din[LIFTS][6];
+        if (f < nf) {
+#pragma unroll
+            for (int i = 0; i < LIFTS; ++i) {
+                const int j = (threadIdx.x / FK_FRAMES) + i * (256 / FK_FRAMES);
+                M3 g;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) g.a[k] = sD[f * LR + j * 9 + k];
+                lift6d_bwd(in[i], g, din[i]);
+            }
+        }
+        // the 6D gradient image goes where the rotations were (rows of L6 floats): nobody reads them any more
+        if (f < nf) {
+#pragma unroll
+            for (int i = 0; i < LIFTS; ++i) {
+                const int j = (threadIdx.x / FK_FRAMES) + i * (256 / FK_FRAMES);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sR[f * L6 + j * 6 + k] = din[i][k];
+            }
+        }
+        __syncthreads();
+        fk_stream_out<NJ * 6>(sR, d_rot + f0 * (NJ * 6), nf);
+    } else {
+        fk_stream_out<NJ * 9>(sD, d_rot + f0 * (NJ * 9), nf);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Any other kinematic tree (fk_layer.py:13-34 takes arbitrary `parents`): table-driven kernels.
+// Requirements (what the reference's loop `for i in 1..J-1: G[i] = G[parents[i]] @ L[i]` needs as well): joint 0 is the
+// root, parents[j] < j, at most 64 joints.  The host turns `parents` into one ancestor bit mask per joint, passed by
+// value; ancestors have smaller indices than descendants and indices grow along a chain, so "bits in ascending order" is
+// the chain root -> parent and "descending" is parent -> root -- no lists, no recursion, no cross-thread sums:
+//   forward   p_j = off_0 + sum_k G_par(k) off_k over the chain = Horner from the leaf upward:
+//             acc = off_j; for a = ancestors of j, nearest first: acc = R_a acc + off_a
+//   backward  dL/dR_k = dL/dR_k(direct) + G_par(k)^T sum_{j below k} dL/dp_j (x) w_kj,   p_j - p_k = G_k w_kj,
+//             w_kj = Horner from j up to (excluding) k;  j is below k  <=>  bit k of anc[j]
+// One thread per (frame, joint); a workgroup stages the (lifted) rotations of 16 frames in LDS first.
+// ------------------------------------------------------------------------------------------------
+constexpr int GEN_MAXJ = 64, GEN_FRAMES = 16;
+struct GenTree {
+    int n;
+    unsigned long long anc[GEN_MAXJ];
+};
+
+__device__ __forceinline__ V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ void ldm(const float* p, M3& R) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R.a[k] = p[k];
+}
+
+// stage rotations (lifted if RD == 6) of the workgroup's frames: sR[f][J*9 + 1]
+template <int RD>
+__device__ __forceinline__ void gen_stage_R(const float* __restrict__ rot, long long f0, int nf, int J, float* sR) {
+    const int LR = J * 9 + 1;
+    if constexpr (RD == 9) {
+        for (int i = threadIdx.x; i < nf * J * 9; i += 256) {
+            const int f = i / (J * 9), r = i - f * (J * 9);
+            sR[f * LR + r] = rot[(size_t)f0 * (J * 9) + i];
+        }
+    } else {
+        for (int i = threadIdx.x; i < nf * J; i += 256) {
+            const int f = i / J, j = i - f * J;
+            float in[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) in[k] = rot[((size_t)(f0 + f) * J + j) * 6 + k];
+            M3 R;
+            lift6d(in, R);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) sR[f * LR + j * 9 + k] = R.a[k];
+        }
+    }
+}
+
+template <int RD, bool PF>
+__global__ __launch_bounds__(256) void fk_fwd_generic_kernel(const float* __restrict__ rot, const float* __restrict__ offs,
+                                                             long long n, float* __restrict__ R_out,
+                                                             float* __restrict__ P_out, GenTree tr) {
+    extern __shared__ __attribute__((aligned(16))) float fk_lds[];
+    const int J = tr.n, LR = J * 9 + 1;
+    float* sR = fk_lds;
+    const long long f0 = (long long)blockIdx.x * GEN_FRAMES;
+    const int nf = n - f0 < GEN_FRAMES ? (int)(n - f0) : GEN_FRAMES;
+    gen_stage_R<RD>(rot, f0, nf, J, sR);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nf * J; i += 256) {
+        const int f = i / J, j = i - f * J;
+        const float* Rf = sR + f * LR;
+        const float* of = offs + (PF ? (size_t)(f0 + f) * (J * 3) : 0);
+        if (R_out) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R_out[((size_t)(f0 + f) * J + j) * 9 + k] = Rf[j * 9 + k];
+        }
+        if (P_out) {
+            V3 acc = ld3(of + j * 3);
+            unsigned long long m = tr.anc[j];
+            while (m) {                                  // nearest ancestor first
+                const int a = 63 - __builtin_clzll(m);
+                m &= ~(1ull << a);
+                M3 R;
+                ldm(Rf + a * 9, R);
+                acc = mulv(R, acc) + ld3(of + a * 3);
+            }
+            float* po = P_out + ((size_t)(f0 + f) * J + j) * 3;
+            po[0] = acc.x; po[1] = acc.y; po[2] = acc.z;
+        }
+    }
+}
+
+template <int RD, bool PF>
+__global__ __launch_bounds__(256) void fk_bwd_generic_kernel(const float* __restrict__ rot, const float* __restrict__ offs,
+                                                             long long n, const float* __restrict__ dR_up,
+                                                             const float* __restrict__ dP_up, float* __restrict__ d_rot,
+                                                             GenTree tr) {
+    extern __shared__ __attribute__((aligned(16))) float fk_lds[];
+    const int J = tr.n, LR = J * 9 + 1, LP = J * 3 + 1;
+    float* sR = fk_lds;
+    float* sDP = sR + GEN_FRAMES * LR;
+    const long long f0 = (long long)blockIdx.x * GEN_FRAMES;
+    const int nf = n - f0 < GEN_FRAMES ? (int)(n - f0) : GEN_FRAMES;
+    gen_stage_R<RD>(rot, f0, nf, J, sR);
+    if (dP_up) {
+        for (int i = threadIdx.x; i < nf * J * 3; i += 256) {
+            const int f = i / (J * 3), r = i - f * (J * 3);
+            sDP[f * LP + r] = dP_up[(size_t)f0 * (J * 3) + i];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nf * J; i += 256) {
+        const int f = i / J, k = i - f * J;
+        const float* Rf = sR + f * LR;
+        const float* of = offs + (PF ? (size_t)(f0 + f) * (J * 3) : 0);
+        M3 M;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) M.a[e] = 0.f;
+        if (dP_up) {
+            const unsigned long long kbit = 1ull << k, above = ~((kbit << 1) - 1ull);
+            for (int j = k + 1; j < J; ++j) {
+                if (!(tr.anc[j] & kbit)) continue;       // j is not below k
+                V3 w = ld3(of + j * 3);
+                unsigned long long m = tr.anc[j] & above;    // the ancestors of j strictly between k and j, nearest first
+                while (m) {
+                    const int a = 63 - __builtin_clzll(m);
+                    m &= ~(1ull << a);
+                    M3 R;
+                    ldm(Rf + a * 9, R);
+                    w = mulv(R, w) + ld3(of + a * 3);
+                }
+                add_outer(M, ld3(sDP + f * LP + j * 3), w);
+            }
+        }
+        M3 dR;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) dR.a[e] = dR_up ? dR_up[((size_t)(f0 + f) * J + k) * 9 + e] : 0.f;
+        if (dP_up) {
+            // G_par(k) = product of the ancestors' rotations, root first (identity for the root)
+            unsigned long long m = tr.anc[k];
+            if (m) {
+                M3 G;
+                bool first = true;
+                while (m) {
+                    const int a = __builtin_ctzll(m);
+                    m &= m - 1;
+                    M3 R;
+                    ldm(Rf + a * 9, R);
+                    G = first ? R : mul(G, R);
+                    first = false;
+                }
+                add_m(dR, mul_tn(G, M));
+            } else {
+                add_m(dR, M);
+            }
+        }
+        float* out = d_rot + ((size_t)(f0 + f) * J + k) * RD;
+        if constexpr (RD == 6) {
+            float in[6], din[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) in[e] = rot[((size_t)(f0 + f) * J + k) * 6 + e];
+            lift6d_bwd(in, dR, din);
+#pragma unroll
+            for (int e = 0; e < 6; ++e) out[e] = din[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) out[e] = dR.a[e];
+        }
+    }
+}
+
+// 0 = the compile-time SMPL-24 tree, 1 = a valid generic tree (tr filled), < 0 = error code
+int classify_tree(const int32_t* parents, int n_joints, GenTree* tr) {
+    if (!parents || n_joints <= 0) return HMVAE_ERR_ARG;
+    bool smpl = n_joints == NJ;
+    for (int j = 0; smpl && j < NJ; ++j) smpl = parents[j] == smpl_parent(j);
+    if (smpl) return 0;
+    if (n_joints > GEN_MAXJ) return HMVAE_ERR_UNSUPPORTED;
+    if (parents[0] >= 0) return HMVAE_ERR_ARG;                       // joint 0 is the root (fk_layer.py:69)
+    tr->n = n_joints;
+    tr->anc[0] = 0;
+    for (int j = 1; j < n_joints; ++j) {
+        if (parents[j] < 0 || parents[j] >= j) return HMVAE_ERR_ARG; // parents come before their children
+        tr->anc[j] = tr->anc[parents[j]] | (1ull << parents[j]);
+    }
+    for (int j = n_joints; j < GEN_MAXJ; ++j) tr->anc[j] = 0;
+    return 1;
 }
 
 }  // namespace
@@ -512,11 +904,24 @@ extern "C" int hmvae_fk_fwd(const float* rot, int32_t rot_dim, const float* offs
                             const int32_t* parents_host, int32_t n_joints, int64_t n_frames, float* R_out,
                             float* pos_out, hmvae_stream_t stream) {
     if (!rot || !offsets || n_frames <= 0 || (rot_dim != 6 && rot_dim != 9)) return HMVAE_ERR_ARG;
-    if (offset_stride != 0 && offset_stride != NJ * 3) return HMVAE_ERR_ARG;
-    if (!is_smpl24(parents_host, n_joints)) return HMVAE_ERR_UNSUPPORTED;
-    dim3 grid((unsigned)((n_frames + FK_FRAMES - 1) / FK_FRAMES)), block(256);
+    if (offset_stride != 0 && offset_stride != (int64_t)n_joints * 3) return HMVAE_ERR_ARG;
+    GenTree tr;
+    const int kind = classify_tree(parents_host, n_joints, &tr);
+    if (kind < 0) return kind;
     hipStream_t s = (hipStream_t)stream;
     const bool pf = offset_stride != 0;
+    if (kind == 1) {
+        dim3 ggrid((unsigned)((n_frames + GEN_FRAMES - 1) / GEN_FRAMES));
+        const size_t lds = sizeof(float) * GEN_FRAMES * (n_joints * 9 + 1);
+#define FK_GEN_FWD(RD_, PF_)                                                                                            \
+        hipLaunchKernelGGL((fk_fwd_generic_kernel<RD_, PF_>), ggrid, dim3(256), lds, s, rot, offsets, (long long)n_frames, \
+                           R_out, pos_out, tr)
+        if (rot_dim == 6) { if (pf) FK_GEN_FWD(6, true); else FK_GEN_FWD(6, false); }
+        else { if (pf) FK_GEN_FWD(9, true); else FK_GEN_FWD(9, false); }
+#undef FK_GEN_FWD
+        return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+    }
+    dim3 grid((unsigned)((n_frames + FK_FRAMES - 1) / FK_FRAMES)), block(256);
 #define FK_FWD_LAUNCH(RD_, PF_) \
     hipLaunchKernelGGL((fk_fwd_aos_kernel<RD_, PF_>), grid, block, 0, s, rot, offsets, (long long)n_frames, R_out, pos_out)
     if (rot_dim == 6) {
@@ -534,16 +939,46 @@ extern "C" int hmvae_fk_bwd(const float* rot, int32_t rot_dim, const float* offs
                             const int32_t* parents_host, int32_t n_joints, int64_t n_frames, const float* dR,
                             const float* dpos, float* d_rot, hmvae_stream_t stream) {
     if (!rot || !offsets || !d_rot || n_frames <= 0 || (rot_dim != 6 && rot_dim != 9)) return HMVAE_ERR_ARG;
-    if (offset_stride != 0 && offset_stride != NJ * 3) return HMVAE_ERR_ARG;
-    if (!is_smpl24(parents_host, n_joints)) return HMVAE_ERR_UNSUPPORTED;
-    dim3 grid((unsigned)((n_frames + 255) / 256)), block(256);
+    if (offset_stride != 0 && offset_stride != (int64_t)n_joints * 3) return HMVAE_ERR_ARG;
+    GenTree tr;
+    const int kind = classify_tree(parents_host, n_joints, &tr);
+    if (kind < 0) return kind;
     hipStream_t s = (hipStream_t)stream;
-    if (rot_dim == 6)
-        hipLaunchKernelGGL(fk_bwd_aos_kernel<6>, grid, block, 0, s, rot, offsets, (long long)offset_stride,
-                           (long long)n_frames, dR, dpos, d_rot);
-    else
-        hipLaunchKernelGGL(fk_bwd_aos_kernel<9>, grid, block, 0, s, rot, offsets, (long long)offset_stride,
-                           (long long)n_frames, dR, dpos, d_rot);
+    const bool pf = offset_stride != 0;
+    if (kind == 1) {
+        dim3 ggrid((unsigned)((n_frames + GEN_FRAMES - 1) / GEN_FRAMES));
+        const size_t glds = sizeof(float) * GEN_FRAMES * ((n_joints * 9 + 1) + (n_joints * 3 + 1));
+#define FK_GEN_BWD(RD_, PF_)                                                                                            \
+        hipLaunchKernelGGL((fk_bwd_generic_kernel<RD_, PF_>), ggrid, dim3(256), glds, s, rot, offsets, (long long)n_frames, \
+                           dR, dpos, d_rot, tr)
+        if (rot_dim == 6) { if (pf) FK_GEN_BWD(6, true); else FK_GEN_BWD(6, false); }
+        else { if (pf) FK_GEN_BWD(9, true); else FK_GEN_BWD(9, false); }
+#undef FK_GEN_BWD
+        return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+    }
+    dim3 grid((unsigned)((n_frames + FK_FRAMES - 1) / FK_FRAMES)), block(256);
+    const size_t lds = sizeof(float) * (FK_FRAMES * 2 * (NJ * 9 + 1) + (pf ? FK_FRAMES * (NJ * 3 + 1) : NJ * 3 + 1) +
+                                        4 * 12 * FK_FRAMES);
+#define FK_BWD_LAUNCH(RD_, PF_)                                                                                        \
+    {                                                                                                                  \
+        static bool attr = false;                                                                                      \
+        if (!attr) {                                                                                                   \
+            if (hipFuncSetAttribute((const void*)fk_bwd_aos_kernel<RD_, PF_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    160 * 1024) != hipSuccess)                                                         \
+                return HMVAE_ERR_LAUNCH;                                                                               \
+            attr = true;                                                                                               \
+        }                                                                                                              \
+        hipLaunchKernelGGL((fk_bwd_aos_kernel<RD_, PF_>), grid, block, lds, s, rot, offsets, (long long)n_frames, dR,  \
+                           dpos, d_rot);                                                                               \
+    }
+    if (rot_dim == 6) {
+        if (pf) FK_BWD_LAUNCH(6, true)
+        else FK_BWD_LAUNCH(6, false)
+    } else {
+        if (pf) FK_BWD_LAUNCH(9, true)
+        else FK_BWD_LAUNCH(9, false)
+    }
+#undef FK_BWD_LAUNCH
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }
 
@@ -636,6 +1071,8 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // Every wave recomputes the trunk's forward chain it needs (<= 4 lifts + 3 products); a limb hands its parent
 // S = sum of dP over the subtree and H = H_c R_c^T + S (x) off_c through LDS (12 floats per frame).
 constexpr int TL_FRAMES = 64;
+// (348 registers, one wave per SIMD: compiled for two waves per SIMD it spills 133 of them and runs 51 instead of 31 us
+// at the training step's 16 384 frames)
 template <bool MK>
 __global__ __launch_bounds__(256) void decode_tail_loss_kernel(const float* __restrict__ dec, const float* __restrict__ g6,
                                                                const float* __restrict__ gR, const float* __restrict__ gP,
@@ -654,98 +1091,10 @@ __global__ __launch_bounds__(256) void decode_tail_loss_kernel(const float* __re
     const bool mine = lane < TL_FRAMES;
     const bool live = mine && b < B;
     TailLoss<MK> io{dec + o, g6 + o, gR + o, gP + o, MK ? mask + o : nullptr, offs, ddec + o, rs, 0.f, 0.f, 0.f, c6, cR, cP};
-    auto hand_over = [&](int slot, const V3& S, const M3& H) {
-        xch[slot][0][lane] = S.x;
-        xch[slot][1][lane] = S.y;
-        xch[slot][2][lane] = S.z;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) xch[slot][3 + i][lane] = H.a[i];
-    };
-    auto limb = [&](auto child, const M3& G, V3 P, V3& S, M3& H) {      // add subtree `child` to its parent's (S, H)
-        constexpr int C = decltype(child)::value;
-        V3 Sc;
-        M3 Hc;
-        fk_bwd_node<C>(G, P, io, Sc, Hc);
-        S = S + Sc;
-        add_m(H, Hc);
-        add_outer(H, Sc, io.off(C));
-    };
-    M3 G0, G3, G6, G9;
-    V3 P0, P3, P6, P9;
-    if (live) {
-        // forward along the trunk (role 1 only needs the root)
-        io.rot(0, G0);
-        P0 = io.off(0);
-        if (role != 1) {
-            M3 R;
-            io.rot(3, R);
-            P3 = P0 + mulv(G0, io.off(3));
-            G3 = mul(G0, R);
-            io.rot(6, R);
-            P6 = P3 + mulv(G3, io.off(6));
-            G6 = mul(G3, R);
-            io.rot(9, R);
-            P9 = P6 + mulv(G6, io.off(9));
-            G9 = mul(G6, R);
-        }
-        V3 S = {0.f, 0.f, 0.f};
-        M3 H;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) H.a[i] = 0.f;
-        if (role == 1) {
-            limb(std::integral_constant<int, 1>{}, G0, P0, S, H);
-            limb(std::integral_constant<int, 2>{}, G0, P0, S, H);
-        } else if (role == 2) {
-            limb(std::integral_constant<int, 13>{}, G9, P9, S, H);
-        } else if (role == 3) {
-            limb(std::integral_constant<int, 14>{}, G9, P9, S, H);
-        } else {
-            limb(std::integral_constant<int, 12>{}, G9, P9, S, H);
-        }
-        hand_over(role, S, H);
-    } else if (mine && b < bp && role == 0) {
+    if (!live && mine && b < bp && role == 0) {
         for (int r = 0; r < NJ * 6; ++r) ddec[o + (size_t)r * rs] = 0.f;   // padded batch columns carry zero gradient
     }
-    __syncthreads();
-    if (role == 0 && live) {
-        // trunk, leaves to root: node J with the sums (S, H) over its children
-        auto node = [&](int J, const M3& Gp, const M3& R, V3 P, V3& S, M3& H, bool root) {
-            const V3 gp = io.grad_P(J, P);
-            S = S + gp;
-            M3 dR;
-            io.grad_R(J, R, dR);
-            add_m(dR, root ? H : mul_tn(Gp, H));
-            io.emit(J, dR);
-            return mul_nt(H, R);                       // H R^T: what the parent's H receives (plus S (x) off_J)
-        };
-        auto take = [&](int slot, V3& S, M3& H) {
-            S = S + V3{xch[slot][0][lane], xch[slot][1][lane], xch[slot][2][lane]};
-#pragma unroll
-            for (int i = 0; i < 9; ++i) H.a[i] += xch[slot][3 + i][lane];
-        };
-        V3 S = {0.f, 0.f, 0.f};
-        M3 H, R;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) H.a[i] = 0.f;
-        take(0, S, H);                                 // head, left arm, right arm hang off joint 9
-        take(2, S, H);
-        take(3, S, H);
-        io.rot(9, R);
-        M3 Hu = node(9, G6, R, P9, S, H, false);
-        H = Hu;
-        add_outer(H, S, io.off(9));
-        io.rot(6, R);
-        Hu = node(6, G3, R, P6, S, H, false);
-        H = Hu;
-        add_outer(H, S, io.off(6));
-        io.rot(3, R);
-        Hu = node(3, G0, R, P3, S, H, false);
-        H = Hu;
-        add_outer(H, S, io.off(3));
-        take(1, S, H);                                 // the legs hang off the root
-        io.rot(0, R);
-        node(0, R, R, P0, S, H, true);
-    }
+    fk_bwd_by_role<TL_FRAMES>(role, lane, live, io, xch);
     const float s6 = wave_sum_f(live ? io.s6 : 0.f), sR = wave_sum_f(live ? io.sR : 0.f), sP = wave_sum_f(live ? io.sP : 0.f);
     if (lane == 0) {
         psum[role][0] = s6;

@@ -11,8 +11,10 @@ from . import topology
 class ForwardKinematicsLayer(torch.nn.Module):
     """forward(rotations, positions=None): rotations (bs, J, 6) or (bs, J, 3, 3) -> joint xyz (bs, J, 3).
 
-    The reference builds (bs,J,4,4) homogeneous matrices and walks the chain with 23 gather/bmm/copy_ steps; here a
-    thread owns a frame and walks the compile-time SMPL-24 tree in registers (csrc/fk_kernels.hip).
+    The reference builds (bs,J,4,4) homogeneous matrices and walks the chain with 23 gather/bmm/copy_ steps; here the
+    SMPL-24 tree is compile-time and a frame's walk is split by subtree over the four waves of a workgroup (32-frame LDS
+    tiles, globals in registers); any other `parents` (joint 0 the root, parents[j] < j, at most 64 joints -- what the
+    reference's loop needs too) runs table-driven kernels with the same results (csrc/fk_kernels.hip).
     """
 
     def __init__(self, device=None, parents=None, positions=None):

@@ -351,7 +351,10 @@ int hmvae_reparam_kl_bwd(const float* dist, const float* eps, const float* dz, f
  * ------------------------------------------------------------------------------------------------ */
 /* my_tools.py:19-39 + fk_layer.py:47-93, AoS.  rot: (n, J, rot_dim) with rot_dim 6 or 9; offsets (J,3) shared
  * (offset_stride 0) or per frame (offset_stride J*3).  R_out (n,J,9) and pos_out (n,J,3) may be NULL.
- * parents_host: J ints on the HOST; the SMPL-24 tree runs the register-resident fast path. */
+ * parents_host: J ints on the HOST (fk_layer.py:13-34 takes any tree).  The SMPL-24 tree runs the compile-time fast path
+ * (subtree per wave, registers + LDS tiles); any other tree with joint 0 as root, parents[j] < j and J <= 64 runs the
+ * table-driven kernels (same results, one thread per (frame, joint)).  Invalid trees: HMVAE_ERR_ARG; J > 64 with a
+ * non-SMPL tree: HMVAE_ERR_UNSUPPORTED. */
 int hmvae_fk_fwd(const float* rot, int32_t rot_dim, const float* offsets, int64_t offset_stride,
                  const int32_t* parents_host, int32_t n_joints, int64_t n_frames, float* R_out, float* pos_out,
                  hmvae_stream_t stream);
