@@ -209,10 +209,8 @@ def fk_microbench(device, iters=20):
                              "traffic": traffic_of("decode_tail_fwd_kernel<true>"),
                              "note": "_decode also returns the frame-major copy of the 6D input: 576 B/frame more to "
                                      "write; achieved / frac count SURVEY's 1728 algorithmic bytes only"},
-            "fk_only_aos": {"kernel": "fk_fwd_aos_kernel<9>", "bytes_per_frame": 1152, "avg_us": avg2 * 1e3,
-                            "achieved": gbs(1152, avg2), "frac": gbs(1152, avg2) / PEAK_HBM_GBS},
-            "fk_rot6d_aos": {"kernel": "fk_fwd_aos_kernel<6>", "bytes_per_frame": 864, "avg_us": avg3 * 1e3,
-                             "achieved": gbs(864, avg3), "frac": gbs(864, avg3) / PEAK_HBM_GBS}}
+            "fk_only_aos": entry("fk_fwd_aos_kernel<9>", 1152, avg2, "ForwardKinematicsLayer on rotation matrices"),
+            "fk_rot6d_aos": entry("fk_fwd_aos_kernel<6>", 864, avg3, "6D in, positions out")}
 
 
 def _host_cores():

@@ -68,6 +68,39 @@ def wait(handle):
         handle.wait()
 
 
+def group_ready():
+    """A process group exists (any world size): collectives can be issued.  A world of ONE rank on RCCL is how the
+    in-graph all-reduce path is exercised on a one-GPU box (the collective is the identity, the capture is real)."""
+    return dist.is_available() and dist.is_initialized()
+
+
+def reduce_between_segments(flat, n_dec, n_hi, n_act, run_b, run_c=None):
+    """The split DDP step after segment A (forward + decoder backward: flat[:n_dec] final) has been queued:
+
+        all-reduce(flat[:n_dec]) asynchronously  ||  run_b()   (encoder backward; with run_c: its coarse half, after
+                                                              which flat[n_dec:n_hi] is final)
+        [all-reduce(flat[n_dec:n_hi]) asynchronously  ||  run_c()   (the fine layers: flat[n_hi:n_act] final)]
+        all-reduce(the remaining slice), wait for the asynchronous ones, sum -> mean over flat[:n_act]
+
+    run_b / run_c only QUEUE device work (graph replays); the collectives run on the backend's own stream behind the work
+    queued before them.  Same result as one all-reduce of flat[:n_act] after everything: the slices are disjoint.
+    graph_step.GraphedStep.run is the caller; tests/test_ddp_gloo_cpu.py drives it with two gloo ranks."""
+    dist_on = is_distributed()
+    handles = [all_reduce_sum_async(flat[:n_dec])] if dist_on else []
+    run_b()
+    start = n_dec
+    if run_c is not None:
+        if dist_on:
+            handles.append(all_reduce_sum_async(flat[n_dec:n_hi]))
+        start = n_hi
+        run_c()
+    if dist_on:
+        all_reduce_sum_(flat[start:n_act])
+        for h in handles:
+            wait(h)
+        scale_(flat[:n_act])
+
+
 def scale_(flat):
     """sum -> mean over the ranks."""
     if is_distributed():

@@ -507,9 +507,12 @@ class VaeEngine(_StepBase):
     # ------------------------------------------------------------------------------------------
     # the training / validation step
     # ------------------------------------------------------------------------------------------
-    def train_step(self, r6, rmat, iterations, eps_list=None, backward=True, repack=True, stage="all"):
+    def train_step(self, r6, rmat, iterations, eps_list=None, backward=True, repack=True, stage="all", slice_hook=None):
         """r6 (B,T,144), rmat (B,T,216): fp32 device tensors.  Returns the `losses` device tensor:
-        [total, kl, rec_6d, rec_rot, rec_pose, kl_level0, kl_deep, 0]."""
+        [total, kl, rec_6d, rec_rot, rec_pose, kl_level0, kl_deep, 0].
+        slice_hook (stage "all" only): called as slice_hook("dec") once every launch that writes the decoder's slice of
+        the gradient bucket has been QUEUED (main + side streams, not joined) and slice_hook("enc_hi") likewise for the
+        coarse encoder half: the in-graph DDP step starts each slice's all-reduce there, beside the rest of the backward."""
         hp, p, P = self.hp, self.p, self.params
         L = p.L
         B, T = r6.shape[0], r6.shape[1]
@@ -579,7 +582,9 @@ class VaeEngine(_StepBase):
             # stage "dec": stop after the decoder's backward (all its gradients final, side streams joined);
             # backward_rest() then runs the latent + encoder part.  DDP uses the cut to overlap the first all-reduce.
             self._bw_ctx = (w, phase2, eps, B, bp)
+            self._slice_hook = slice_hook if stage == "all" else None
             self._backward(w, phase2, eps, B, bp, part="dec" if stage == "dec" else "all")
+            self._slice_hook = None
             if stage != "dec":
                 self.assign_grads(phase2)
         return ls
@@ -601,6 +606,8 @@ class VaeEngine(_StepBase):
             if part == "dec":
                 self._join()
                 return
+            if getattr(self, "_slice_hook", None) is not None:
+                self._slice_hook("dec")
         self._backward_encoder(w, phase2, eps, B, bp, enc_w, enc_b, part if part in ("enc_hi", "enc_lo") else "all")
 
     def _backward_decoder(self, w, phase2, bp, dconv):
@@ -650,11 +657,15 @@ class VaeEngine(_StepBase):
         hp, p, L = self.hp, self.p, self.p.L
         if part != "enc_lo":
             self._backward_encoder_head(w, phase2, eps, B, bp)
-            lo_layer = self.enc_cut if part == "enc_hi" else 0
+            hook = getattr(self, "_slice_hook", None) if part == "all" else None
+            lo_layer = self.enc_cut if (part == "enc_hi" or hook is not None) else 0
             self._backward_encoder_layers(w, phase2, bp, enc_w, enc_b, L - 1, lo_layer)
             if part == "enc_hi":
                 self._join()
                 return
+            if hook is not None:
+                hook("enc_hi")
+                self._backward_encoder_layers(w, phase2, bp, enc_w, enc_b, self.enc_cut - 1, 0)
         else:
             self._backward_encoder_layers(w, phase2, bp, enc_w, enc_b, self.enc_cut - 1, 0)
         self._join()

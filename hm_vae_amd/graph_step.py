@@ -107,6 +107,14 @@ class GraphedStep:
         # HMVAE_DDP_BUCKETS=3 (default): the encoder's backward is cut once more -- coarse layers | fine layers -- so that
         # only the fine layers' few MB are all-reduced exposed; 2: [decoder | encoder]
         self.buckets = int(os.environ.get("HMVAE_DDP_BUCKETS", "3"))
+        # HMVAE_DDP_INGRAPH=1: ONE graph for the whole DDP step -- the slices' all-reduces are captured inside it, issued
+        # from a helper stream that waits for exactly the launches that write the slice (no join of the side streams, no
+        # graph cut: the two cuts of the multi-graph step cost 3.6 % + 4.6 % of a one-GPU step).  Needs a backend whose
+        # collectives can be captured (RCCL); exercised on one GPU with a world of one rank.  Off by default until it has
+        # run on a multi-GPU node.
+        self.ingraph = os.environ.get("HMVAE_DDP_INGRAPH", "0") == "1" and self.is_vae
+        self._comm = None
+        self._handles = []
         self._pinned = None
         self.phase2 = None
         self.warmup = warmup
@@ -141,29 +149,41 @@ class GraphedStep:
     def _optim(self):
         self.tr.gen_opt.step()
 
+    # -- the in-graph DDP step --
+    def _slice_hook(self, which):
+        """Start the all-reduce of one slice of the gradient bucket: the collective is issued from the helper stream
+        self._comm, which waits for the main stream and for every side stream forked so far -- i.e. for every launch
+        that writes the slice -- while the main stream goes on with the backward pass."""
+        import torch.distributed as dist
+        eng = self.model.engine()
+        n = eng.active_grad_floats(self.phase2)
+        lo, hi = {"dec": (0, eng.n_dec_floats), "enc_hi": (eng.n_dec_floats, eng.n_hi_floats),
+                  "rest": (eng.n_hi_floats, n)}[which]
+        main = torch.cuda.current_stream()
+        eng._stream_wait(self._comm, main, ("comm_main", which))
+        if eng._side is not None:
+            for i in sorted(eng._forked):
+                eng._stream_wait(self._comm, eng._side[i], ("comm_side", which, i))
+        if hi > lo:
+            with torch.cuda.stream(self._comm):
+                self._handles.append(dist.all_reduce(eng.flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def _ingraph_body(self):
+        import torch.distributed as dist
+        eng = self.model.engine()
+        self._handles = []
+        self.losses = eng.train_step(self.r6, self.rmat, self.it, eps_list=None, backward=True, slice_hook=self._slice_hook)
+        self._slice_hook("rest")                       # (the step's final join has happened: only the main stream is waited for)
+        for h in self._handles:
+            h.wait()                                   # the current stream waits for the collective
+        eng._stream_wait(torch.cuda.current_stream(), self._comm, "comm_join")
+        eng.flat_grad[:eng.active_grad_floats(self.phase2)].mul_(1.0 / dist.get_world_size())
+        self._optim()
+
     def _reduce(self):
         if ddp.is_distributed():
             eng = self._engine()
             ddp.all_reduce_mean_(eng.flat_grad[:eng.active_grad_floats(self.phase2)])
-
-    def _reduce_dec_async(self):
-        """All-reduce of the decoder's slice of the bucket, asynchronous: RCCL runs it on its own stream once the work
-        queued so far (forward + decoder backward) is done, i.e. beside the encoder's backward."""
-        eng = self.model.engine()
-        return ddp.all_reduce_sum_async(eng.flat_grad[:eng.n_dec_floats])
-
-    def _reduce_hi_async(self):
-        """The coarse encoder half's slice, asynchronous beside the fine layers' backward (queued behind the decoder's)."""
-        eng = self.model.engine()
-        return ddp.all_reduce_sum_async(eng.flat_grad[eng.n_dec_floats:eng.n_hi_floats])
-
-    def _reduce_enc_and_finish(self, handles, start=None):
-        eng = self.model.engine()
-        n = eng.active_grad_floats(self.phase2)
-        ddp.all_reduce_sum_(eng.flat_grad[eng.n_dec_floats if start is None else start:n])
-        for h in handles:
-            ddp.wait(h)
-        ddp.scale_(eng.flat_grad[:n])
 
     def _phase2(self):
         return self.is_vae and self.it >= self.cfg['iteration_interval']
@@ -206,13 +226,19 @@ class GraphedStep:
         # (the warm-up steps are real optimiser steps: parameters and Adam state are put back afterwards, so a run with
         # graph replay takes exactly the steps an eager run takes)
         snap = self._snapshot()
+        use_ingraph = self.ingraph and ddp.group_ready()
+        if use_ingraph and self._comm is None:
+            self._comm = torch.cuda.Stream()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(self.warmup):
-                self._fwd_bwd()
-                self._reduce()
-                self._optim()
+                if use_ingraph:
+                    self._ingraph_body()
+                else:
+                    self._fwd_bwd()
+                    self._reduce()
+                    self._optim()
                 self.tr.gen_opt.advance_host_steps(0)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -223,7 +249,13 @@ class GraphedStep:
         g1 = torch.cuda.CUDAGraph()
         g2 = None
         self.g1b = self.g1c = None
-        if ddp.is_distributed() or self.force_split:
+        if use_ingraph:
+            host_before = dict(self.tr.gen_opt._host_step)
+            with torch.cuda.graph(g1):
+                self._ingraph_body()
+            self.tr.gen_opt._host_step = host_before
+            self.tr.gen_opt.resync_device_steps()
+        elif ddp.is_distributed() or self.force_split:
             if self.split:
                 # three graphs: [forward + decoder backward] -> async all-reduce of the decoder gradients ||
                 # [encoder backward] -> all-reduce of the rest -> [optimiser]
@@ -282,17 +314,10 @@ class GraphedStep:
         g1.replay()
         if g2 is not None:
             if self.g1b is not None:
-                dist = ddp.is_distributed()
-                hs = [self._reduce_dec_async()] if dist else []
-                self.g1b.replay()
-                start = None
-                if self.g1c is not None:
-                    if dist:
-                        hs.append(self._reduce_hi_async())
-                        start = self.model.engine().n_hi_floats
-                    self.g1c.replay()
-                if dist:
-                    self._reduce_enc_and_finish(hs, start)
+                eng = self.model.engine()
+                ddp.reduce_between_segments(eng.flat_grad, eng.n_dec_floats, eng.n_hi_floats,
+                                            eng.active_grad_floats(self.phase2), self.g1b.replay,
+                                            self.g1c.replay if self.g1c is not None else None)
             else:
                 self._reduce()
             g2.replay()

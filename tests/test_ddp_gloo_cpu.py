@@ -188,6 +188,64 @@ def test_two_rank_trajectory_bucket_allreduce(tmp_path):
     assert worst < 5e-5, worst
 
 
+def _segments_worker(rank, world, port, out_dir, three):
+    """ddp.reduce_between_segments as GraphedStep.run drives it, on CPU tensors over gloo: segment B / C are closures that
+    write their slices of the bucket when they run (the role of the graph replays), so a slice reduced before its segment
+    ran, a wrong boundary or a missing wait shows up as a wrong mean."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from hm_vae_amd import ddp
+    from hm_vae_amd.engine import VaeEngine
+    from helpers import load_cfg, offsets
+    from oracle import hmvae_oracle as O
+    ddp.init_from_env(backend="gloo")
+    cfg = load_cfg("len8")
+    plan = O.Plan(cfg)
+    eng = VaeEngine(cfg, O.name_seeded_params(plan), offsets(), torch.device("cpu"))        # the real bucket layout, planned on CPU
+    eng.grad_layout()
+    n_dec, n_hi, n_act = eng.n_dec_floats, eng.n_hi_floats, eng.active_grad_floats(True)
+    assert 0 < n_dec < n_hi < n_act <= eng.flat_grad.numel()
+    g = torch.Generator().manual_seed(11 + rank)
+    full = torch.randn(eng.flat_grad.numel(), generator=g)                                  # this rank's complete gradient
+    flat = eng.flat_grad
+    flat.zero_()
+    flat[:n_dec] = full[:n_dec]                                                             # segment A has run
+    order = []
+
+    def seg_b():
+        order.append("b")
+        hi = n_hi if three else n_act
+        flat[n_dec:hi] = full[n_dec:hi]
+
+    def seg_c():
+        order.append("c")
+        flat[n_hi:n_act] = full[n_hi:n_act]
+
+    ddp.reduce_between_segments(flat, n_dec, n_hi, n_act, seg_b, seg_c if three else None)
+    assert order == (["b", "c"] if three else ["b"])
+    both = [torch.zeros_like(full) for _ in range(world)]
+    dist.all_gather(both, full)
+    want = sum(both) / world
+    err = float((flat[:n_act] - want[:n_act]).abs().max())
+    tail_untouched = bool((flat[n_act:] == 0).all())
+    if rank == 0:
+        with open(os.path.join(out_dir, "result_seg_%d.txt" % int(three)), "w") as f:
+            f.write("%.3e %d" % (err, int(tail_untouched)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("three", [False, True])
+def test_two_rank_split_step_reduce_sequence(tmp_path, three):
+    """The multi-graph DDP step's collective sequence (two or three bucket slices, the first ones asynchronous) gives the
+    mean of the ranks' complete gradients on the engine's real bucket boundaries, and leaves the inactive tail alone."""
+    port = _free_port()
+    mp.spawn(_segments_worker, args=(2, port, str(tmp_path), three), nprocs=2, join=True)
+    err, tail = open(os.path.join(str(tmp_path), "result_seg_%d.txt" % int(three))).read().split()
+    assert float(err) < 1e-6 and tail == "1"
+
+
 def test_single_process_helpers_are_noops():
     from hm_vae_amd import ddp
     assert not ddp.is_distributed() and ddp.rank() == 0 and ddp.world_size() == 1

@@ -232,8 +232,8 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     assert it == 1
     tr2.model.eps_override = golden_eps(g)
     r2 = tr2.gen_update(batch, cfg2, it, False)
-    # two trainers, each timing its own kernel variants: equal up to fp32 summation order
-    assert rel_err(np.array(r2), np.array(r_next)) < 5e-6
+    # two trainers launching the same kernel variants (ops._tune_memo): the resumed step repeats the original one
+    assert rel_err(np.array(r2), np.array(r_next)) < 1e-6
     sd = torch.load(str(tmp_path / "gen_00000001.pt"), map_location="cpu", weights_only=True)["state_dict"]
     assert list(sd.keys()) == meta["state_dict_keys"]
     opt = torch.load(str(tmp_path / "optimizer.pt"), map_location="cpu", weights_only=True)["gen"]
@@ -276,14 +276,50 @@ def test_graph_replay_split_path_matches_single_graph(dev, monkeypatch):
         assert (step.g1c is not None) == (force == "1" and buckets == "3")
         params = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters() if p.requires_grad]).cpu().numpy()
         outs.append((np.array(losses), params))
-    # step 1 is the same arithmetic up to the autotuner's choice of summation order; later steps amplify that noise
-    # through training (ill-conditioned Adam updates of ~eps-sized gradients), so they get a looser bound
-    # (two engines, each timing its own kernel variants: observed up to 1.3e-6 between fp32 summation orders)
+    # The engines of one process launch the same kernel variants (ops._tune_memo), and cutting the graph changes neither a
+    # kernel nor its operands: every loss of every step and every parameter must come out the same to the last bit or two
+    # (round 1 compared engines that had each timed their own variants and needed 5e-4 on the later steps).
     for k in (1, 2):
-        assert rel_err(outs[k][0][0, :5], outs[0][0][0, :5]) < 5e-6
-        assert rel_err(outs[k][0][:, :5], outs[0][0][:, :5]) < 5e-4
-        frac_close = float((np.abs(outs[k][1] - outs[0][1]) < 1e-5).mean())
-        assert frac_close > 0.999, (k, frac_close)
+        assert rel_err(outs[k][0][:, :5], outs[0][0][:, :5]) < 2e-6
+        frac_close = float((np.abs(outs[k][1] - outs[0][1]) < 1e-7).mean())
+        assert frac_close > 0.9999, (k, frac_close)
+
+
+def test_ingraph_allreduce_world_of_one(dev, monkeypatch):
+    """HMVAE_DDP_INGRAPH=1: the whole DDP step, slice all-reduces included, captured in ONE hipGraph (RCCL collectives
+    issued from a helper stream behind exactly the launches that write each slice).  On a one-GPU box the process group
+    has one rank -- the collectives are identities, the capture, the stream dependencies and the replay are real -- so the
+    run must reproduce the plain single-graph step: every loss of four steps and the parameters after them."""
+    import socket
+    import torch.distributed as dist
+    from hm_vae_amd.graph_step import GraphedStep
+    g, meta = load_model_golden("len64")
+    batch = golden_batch(g)
+    outs = []
+    for ingraph in (False, True):
+        cfg, plan, tr, seeded = make_trainer("len64", dev)
+        torch.manual_seed(77)
+        if ingraph:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+            s.close()
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+            monkeypatch.setenv("HMVAE_DDP_INGRAPH", "1")
+        try:
+            step = GraphedStep(tr, cfg, batch, cfg["iteration_interval"], use_graph=True, warmup=1)
+            assert step.ingraph == ingraph
+            losses = [step.run() for _ in range(4)]
+            if ingraph:
+                assert step.graphs[1] is None and step.g1b is None and len(step._handles) == 3     # one graph, three slices
+        finally:
+            if ingraph:
+                torch.cuda.synchronize()
+                dist.destroy_process_group()
+        params = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters() if p.requires_grad]).cpu().numpy()
+        outs.append((np.array(losses), params))
+    assert rel_err(outs[1][0][:, :5], outs[0][0][:, :5]) < 2e-6
+    assert float((np.abs(outs[1][1] - outs[0][1]) < 1e-6).mean()) > 0.9999
 
 
 def test_bench_two_rank_launch_rehearsal(dev, tmp_path):
@@ -339,11 +375,11 @@ def test_graph_replay_across_the_phase_switch(dev):
         params = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters() if p.requires_grad]).cpu().numpy()
         outs.append((np.array(losses), params, head))
         assert np.abs(head - seeded["enc.latent_enc_layers.0.weight"].numpy()).max() > 0     # it did start to train
-    assert rel_err(outs[1][0][:, :5], outs[0][0][:, :5]) < 5e-4
-    # seven Adam steps of 1e-4 each: a parameter whose gradient is rounding noise moves by +-lr per step in either run
-    # (two engines, each with its own kernel variants), so compare at the size of one step, not of the noise
-    frac_close = float((np.abs(outs[1][1] - outs[0][1]) < 1e-4).mean())
-    assert frac_close > 0.999, frac_close
+    # same kernel variants in both engines (ops._tune_memo), same operands: graph replay and eager launches agree to
+    # the last bits over all seven steps (round 1, with per-engine variant choices, needed 5e-4 and one lr step)
+    assert rel_err(outs[1][0][:, :5], outs[0][0][:, :5]) < 2e-6
+    frac_close = float((np.abs(outs[1][1] - outs[0][1]) < 1e-7).mean())
+    assert frac_close > 0.9999, frac_close
 
 
 def test_cli_with_graph_replay(dev, tmp_path):

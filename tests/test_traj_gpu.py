@@ -277,6 +277,5 @@ def test_traj_graph_replay_matches_eager(dev):
         graph.append(gs.run())
     assert len(graph[0]) == 9
     e, r = np.array(eager), np.array(graph)
-    assert rel_err(r[0], e[0]) < 5e-6            # two engines, each timing its own kernel variants
-    assert rel_err(r, e) < 5e-4                  # later steps amplify the summation-order noise through Adam
+    assert rel_err(r, e) < 2e-6                  # both engines launch the same kernel variants (ops._tune_memo): same bits
     assert r[3, 0] < r[0, 0]                     # and it trains

@@ -14,13 +14,23 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+# "fk": the passes of tools/profile_fk.sh -- kernels keep their template arguments (decode_tail_fwd_kernel<true> and <false>
+# are different kernels of bench.py's fk_roofline), outputs are profiles/<tag>_fk_*
+fk = len(sys.argv) > 2 and sys.argv[2] == "fk"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sub_prefix = "fk_" if fk else ""
 
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    return name.split("(")[0].split("<")[0].strip()
+    base = name.split("(")[0]
+    if not fk:
+        return base.split("<")[0].strip()
+    # "decode_tail_fwd_kernel<true, 1>" -> "decode_tail_fwd_kernel<true>", "fk_fwd_aos_kernel<9, false>" -> "...<9>"
+    if "<" in base:
+        head, args = base.split("<", 1)
+        return "%s<%s>" % (head.strip(), args.split(",")[0].strip().rstrip(">"))
+    return base.strip()
 
 
 def newest(pattern):
@@ -31,7 +41,7 @@ def newest(pattern):
 
 def collect(sub, counter):
     out = collections.defaultdict(list)
-    for f in newest(os.path.join(root, "gpurun_out", "prof_%s_%s" % (tag, sub), "**", "*counter_collection.csv")):
+    for f in newest(os.path.join(root, "gpurun_out", "prof_%s_%s%s" % (tag, sub_prefix, sub), "**", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 out[short(r["Kernel_Name"])].append(float(r["Counter_Value"]) * 1024.0)
@@ -49,9 +59,9 @@ for k in sorted(set(fetch) | set(write)):
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 json.dump({"tag": tag, "unit": "bytes per launch (mean over all launches of the kernel in the run)",
            "correction": "FETCH_SIZE*1024*2 (gfx950 half-count), WRITE_SIZE*1024", "kernels": res},
-          open(os.path.join(root, "profiles", "%s_traffic.json" % tag), "w"), indent=1)
-for f in newest(os.path.join(root, "gpurun_out", "prof_%s_stats" % tag, "**", "*kernel_stats.csv")):
-    shutil.copy(f, os.path.join(root, "profiles", "%s_kernel_stats.csv" % tag))
+          open(os.path.join(root, "profiles", "%s_%straffic.json" % (tag, sub_prefix)), "w"), indent=1)
+for f in newest(os.path.join(root, "gpurun_out", "prof_%s_%sstats" % (tag, sub_prefix), "**", "*kernel_stats.csv")):
+    shutil.copy(f, os.path.join(root, "profiles", "%s_%skernel_stats.csv" % (tag, sub_prefix)))
 for f in newest(os.path.join(root, "gpurun_out", "prof_%s_serial" % tag, "**", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(root, "profiles", "%s_serial_kernel_stats.csv" % tag))
 for k, v in res.items():
