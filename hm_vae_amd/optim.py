@@ -76,8 +76,7 @@ class HipAdam(torch.optim.Adam):
                     ent = dict(tab=torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(plist[0].device),
                                step=torch.full((1,), stepval, dtype=torch.int32, device=plist[0].device),
                                host=stepval, max_numel=max(p.numel() for p in plist), params=list(plist), live=False)
-                    if len(self._cache) > 16:
-                        self._cache.clear()
+                    self._evict()
                     self._cache[ptrs] = ent
                 if ent['host'] == stepval:
                     ent['step'].add_(1)
@@ -90,6 +89,19 @@ class HipAdam(torch.optim.Adam):
                 for p in plist:
                     self._host_step[p] = stepval + 1
         return None
+
+    MAX_CACHE = 16
+
+    def _evict(self):
+        """Make room in the table cache: drop the OLDEST entries that no captured hipGraph addresses.  An entry marked
+        live is baked into a graph (its `tab` and `step` device tensors are what the replay reads and counts in): it is
+        never dropped, and a cache full of live entries simply grows."""
+        if len(self._cache) < self.MAX_CACHE:
+            return
+        for key in [k for k, e in self._cache.items() if not e.get('live')]:
+            if len(self._cache) < self.MAX_CACHE:
+                break
+            del self._cache[key]
 
     def advance_host_steps(self, n):
         """A graph replay advances the device step counters but not the host mirror; account for it here."""

@@ -94,8 +94,14 @@ class LatentRefiner:
         self.losses = torch.zeros(8, device=dev)
 
     def _decoder_names(self):
-        """The tensors of `dec` the step reads (the two dead middle latent heads receive no gradient in the reference
-        either: their regulariser term is identically zero)."""
+        """The trainable tensors of `dec` proper: the convolutions and ALL latent heads.  The two middle heads feed nothing
+        (seq_two_hier_sa_vae.py:264-272) but the reference's decoder optimiser holds them (:1343-1344) and l_reg_decoder
+        sums over them (:1371-1373): their gradient is that regulariser's (zero at first) plus Adam's weight decay, so
+        they drift and enter the reported l_reg_decoder / l_total -- reproduced here.  NOT reproduced: the reference's
+        deep copy of the decoder also carries a copy of the ENCODER (`dec.enc.*`, :180), 6.3 M more parameters that
+        decay the same way and add to the reported regulariser without ever touching an output; with weight_decay != 0
+        columns 0, 1 and 6 of the history therefore differ from what the released routine would print (it cannot run:
+        parity unpinned either way)."""
         eng, L = self.eng, self.eng.p.L
         _, _, dconv = eng.names()
         names = []
@@ -103,7 +109,7 @@ class LatentRefiner:
             names.append(dconv[i] + ".weight")
             if eng.p.dec_bias[i]:
                 names.append(dconv[i] + ".bias")
-        for i in (0, L - 1):
+        for i in range(L):
             names += ["dec.latent_dec_layers.%d.weight" % i, "dec.latent_dec_layers.%d.bias" % i]
         return names
 

@@ -267,17 +267,48 @@ class DeviceMotionLoader:
             yield self.ds.assemble(self.describe(self.sample_batch(order[s:s + self.B])), self.T, self.root_rot)
 
 
+TRAIN_IDS = "train_all_amass_motion_data.json"        # utils_motion_vae.py:205-206
+VAL_IDS = "val_all_amass_motion_data.json"
+
+
+def _split_files(data_folder, config):
+    """(train ids json, val ids json) the way the reference factory finds them (utils_motion_vae.py:196-206): under
+    <data_root>/for_all_data_motion_model/, here also accepted next to the npy files or named in the config
+    ('train_ids_json' / 'val_ids_json').  (None, None) when there is no split."""
+    cands = [(config.get("train_ids_json"), config.get("val_ids_json"))]
+    for d in (data_folder, os.path.join(data_folder, "for_all_data_motion_model"),
+              os.path.join(os.path.dirname(os.path.abspath(data_folder)), "for_all_data_motion_model")):
+        cands.append((os.path.join(d, TRAIN_IDS), os.path.join(d, VAL_IDS)))
+    for tr, va in cands:
+        if tr and va and os.path.exists(tr) and os.path.exists(va):
+            return tr, va
+    return None, None
+
+
 def get_train_loaders_all_data_seq(config, device=None, data_folder=None, n_batches=64):
-    """Same name as the reference factory (utils_motion_vae.py:194-232): returns (train, val, test) loaders."""
+    """Same name as the reference factory (utils_motion_vae.py:194-232): returns (train, val, test) loaders.
+
+    With a data folder: train draws from the sequences of train_all_amass_motion_data.json, val and test from those of
+    val_all_amass_motion_data.json (two device-resident datasets), exactly the reference's split.  If the id files are not
+    there the folder is ONE pool: that is said loudly and the val / test loaders are None -- the training script then
+    skips validation instead of printing training-set losses under a 'Val' label."""
     B, T = config["batch_size"], config["train_seq_len"]
     if data_folder:
         dev = device or torch.device("cuda")
         from . import ddp
-        ds = DeviceMotionDataset(data_folder, dev)
         fps, rot = bool(config.get("fps_aug_flag", False)), bool(config.get("random_root_rot_flag", False))
         r = 1000 * ddp.rank()            # every rank draws its own clips (one process per GPU, batch_size sequences each)
-        return (DeviceMotionLoader(ds, B, T, fps, rot, True, r), DeviceMotionLoader(ds, B, T, fps, rot, False, r + 1),
-                DeviceMotionLoader(ds, 1, T, fps, rot, True, r + 2))
+        tr_json, va_json = _split_files(data_folder, config)
+        if tr_json is None:
+            import warnings
+            warnings.warn("hm_vae_amd: no %s / %s for %s: every sequence is used for training and validation is OFF"
+                          % (TRAIN_IDS, VAL_IDS, data_folder))
+            ds = DeviceMotionDataset(data_folder, dev)
+            return (DeviceMotionLoader(ds, B, T, fps, rot, True, r), None, None)
+        ds_tr = DeviceMotionDataset(data_folder, dev, ids_json=tr_json)
+        ds_va = DeviceMotionDataset(data_folder, dev, ids_json=va_json)
+        return (DeviceMotionLoader(ds_tr, B, T, fps, rot, True, r), DeviceMotionLoader(ds_va, B, T, fps, rot, False, r + 1),
+                DeviceMotionLoader(ds_va, B, T, fps, rot, True, r + 2))
     dev = device or (torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"))
     wp = config.get("model_name") == "TrajectoryModel"
     from . import ddp

@@ -120,3 +120,20 @@ def test_retired_graphs_are_parked_not_destroyed():
     finally:
         graph_step._RETIRED[:] = before
         graph_step.PARK, graph_step._warned[0] = park, warned
+
+
+def test_adam_table_cache_never_evicts_live_entries():
+    """HipAdam's table cache: entries a captured hipGraph addresses (`live`) hold the device tensors the replay reads and
+    counts in -- eviction may only drop the others, oldest first."""
+    from hm_vae_amd.optim import HipAdam
+    opt = HipAdam([torch.nn.Parameter(torch.zeros(3))], lr=1e-3)
+    for i in range(opt.MAX_CACHE):
+        opt._cache[("k", i)] = dict(live=(i % 4 == 0), tab=object(), step=object())
+    opt._evict()
+    assert len(opt._cache) == opt.MAX_CACHE - 1
+    assert ("k", 1) not in opt._cache and ("k", 0) in opt._cache and ("k", 2) in opt._cache       # oldest non-live one went
+    for k in list(opt._cache):
+        opt._cache[k]["live"] = True
+    opt._cache[("k", "new")] = dict(live=True)
+    opt._evict()                                                                                      # nothing evictable: it grows
+    assert len(opt._cache) == opt.MAX_CACHE and all(e["live"] for e in opt._cache.values())

@@ -107,3 +107,31 @@ def test_device_loader_host_sampler_follows_the_reference_rules():
         ds.assemble(bad, T, False)
     with pytest.raises(_lib.HmvaeError):                      # no CPU path: the table must live on a HIP device
         ds.assemble(ld.describe([ld.sample_clip(0)]), T, True)
+
+
+def test_factory_keeps_the_reference_train_val_split(tmp_path):
+    """get_train_loaders_all_data_seq (utils_motion_vae.py:194-232): train draws from train_all_amass_motion_data.json,
+    val and test from val_all_amass_motion_data.json; without the id files the folder is one training pool and there is
+    NO validation loader (never training-set losses under a 'Val' label)."""
+    import json
+    import warnings
+    from hm_vae_amd.utils_motion_vae import get_train_loaders_all_data_seq, TRAIN_IDS, VAL_IDS
+    rng = np.random.default_rng(0)
+    folder = tmp_path / "npy"
+    folder.mkdir()
+    lens = {"a.npy": 40, "b.npy": 50, "c.npy": 60, "d.npy": 70, "e.npy": 80}
+    for name, n in lens.items():
+        np.save(str(folder / name), rng.standard_normal((n, 579)).astype(np.float32))
+    cfg = dict(batch_size=2, train_seq_len=16, fps_aug_flag=False, random_root_rot_flag=False)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        tr, va, te = get_train_loaders_all_data_seq(cfg, "cpu", str(folder))
+    assert va is None and te is None and len(tr.ds) == 5
+    assert any("validation is OFF" in str(w.message) for w in seen)
+    meta = tmp_path / "for_all_data_motion_model"
+    meta.mkdir()
+    json.dump({"0": "a.npy", "1": "c.npy", "2": "e.npy"}, open(str(meta / TRAIN_IDS), "w"))
+    json.dump({"0": "b.npy", "1": "d.npy"}, open(str(meta / VAL_IDS), "w"))
+    tr, va, te = get_train_loaders_all_data_seq(cfg, "cpu", str(folder))
+    assert list(tr.ds.seq_len) == [40, 60, 80] and list(va.ds.seq_len) == [50, 70]
+    assert te.ds is va.ds and tr.shuffle and not va.shuffle and te.shuffle

@@ -171,13 +171,31 @@ def test_short_loop_matches_oracle_adam(dev, monkeypatch):
     zd = torch.randn(B, plan.edge_num[plan.L], plan.lat_dim[plan.L - 1], generator=g)
     ref = refine.LatentRefiner(model, cfg, target, mask, z0, zd)
     names = ref._decoder_names()
-    hist = ref.run(6)
+    orc = O.OracleVAE(cfg, seeded, offsets=offsets())
+    anchor = {n: orc.params[n].detach().clone() for n in names}
+    # (1) Every point of the HIP trajectory, teacher-forced: the oracle evaluates the losses AT the refiner's current
+    # latents and decoder, so each iteration is a single-step comparison at 1e-4 -- what the kernels compute -- free of
+    # what Adam does to rounding differences over several steps.
+    rows = []
+    for i in range(6):
+        zs, zdp = ref.z_shallow.detach().cpu().clone(), ref.z_deep.detach().cpu().clone()
+        with torch.no_grad():
+            for n in names:
+                orc.params[n].copy_(model.engine().params[n].detach().cpu())
+        o = orc.refine_forward(zs, zdp, target, mask, anchor=anchor, backward=False)
+        want_i = np.array([float(o[k]) for k in ("total", "rec_6d", "rec_rot", "rec_pose", "reg")])
+        rows.append(ref.step().detach().cpu().numpy().copy())
+        assert rel_err(rows[-1][[0, 2, 3, 4, 5]], want_i) < TOL, (i, rows[-1], want_i)
+        if i > 3:                                     # the decoder has moved: its regulariser against the oracle's
+            assert abs(rows[-1][6] - float(o["reg_decoder"])) < 1e-3 * float(o["reg_decoder"]) + 1e-12
+    hist = np.array(rows)
     ref.restore()
     for n in names:                                   # the model's decoder is what it was
         assert torch.equal(model.engine().params[n].detach().cpu(), seeded[n]), n
 
+    # (2) the free-running trajectories (HipAdam vs torch.optim.Adam on the oracle) stay together: sign-like Adam steps at
+    # lr 0.1 amplify fp32 rounding differences, hence the looser bound on this part only
     orc = O.OracleVAE(cfg, seeded, offsets=offsets())
-    anchor = {n: orc.params[n].detach().clone() for n in names}
     z0o, zdo = z0.clone().requires_grad_(True), zd.clone().requires_grad_(True)
     opt_z = torch.optim.Adam([z0o, zdo], lr=cfg["opt_lr"], weight_decay=cfg["weight_decay"])
     opt_d = torch.optim.Adam([orc.params[n] for n in names], lr=cfg["opt_lr"] * 0.001, weight_decay=cfg["weight_decay"])

@@ -81,7 +81,7 @@ def main():
             if it % 50 == 0 and rank == 0:
                 print('Training: Total loss: %.4f, KL loss: %.8f, Rec 6D loss: %.4f, Rec Rot loss: %.4f, Rec Pose loss: %.4f, '
                       'Rec joint pos loss: %.4f, Rec root v loss: %.4f, Rec linear v loss: %.4f, Rec angular v loss: %.4f' % out)
-            if (iterations + 1) % config['validation_iter'] == 0:
+            if val_loader is not None and (iterations + 1) % config['validation_iter'] == 0:
                 with torch.no_grad():
                     for val_it, val_data in enumerate(val_loader):
                         if val_it >= 50:
@@ -90,7 +90,7 @@ def main():
                         if rank == 0 and val_it == 0:
                             print('Val Total loss: %.4f, Val KL loss: %.8f, Val Rec 6D loss: %.4f, Val Rec Rot loss: %.4f, '
                                   'Val Rec Pose loss: %.4f' % vout[:5])
-            if (iterations + 1) % config['image_save_iter'] == 0 and rank == 0:
+            if test_loader is not None and (iterations + 1) % config['image_save_iter'] == 0 and rank == 0:
                 with torch.no_grad():
                     for test_it, test_data in enumerate(test_loader):
                         if test_it >= opts.test_batch_size:
