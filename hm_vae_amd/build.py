@@ -20,8 +20,8 @@ def _newer(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
-    extra = ["-DHMVAE_STAMP"] if os.environ.get("HMVAE_STAMP") else []      # diagnostic build (tools/stamp_gemm.py)
-    if os.environ.get("HMVAE_ABLATE"):                                        # diagnostic build (tools/ablate_v3.py)
+    extra = ["-DHMVAE_STAMP"] if os.environ.get("HMVAE_STAMP") else []      # diagnostic build: in-kernel s_memtime stamps
+    if os.environ.get("HMVAE_ABLATE"):                                        # diagnostic build: timing ablations of the v3 kernel
         extra.append("-DHMVAE_ABLATE")
     if extra:
         force = True

@@ -1,7 +1,7 @@
 // gemm_v3.hip — window gather-GEMM for the temporal convolutions (third generation), persistent and K-streamed.
 //
 // Same contract as hmvae_gather_gemm_v2 for SkeletonConv forward / backward-data (reference skeleton.py:95-105).
-// What the v2 profiles and the ablations of the first v3 draft showed (tools/ablate_v3.py):
+// What the v2 profiles and the ablations of the first v3 draft showed (round-1 ablation builds, -DHMVAE_ABLATE):
 //   * v2 spends ~6 non-matrix instructions per MFMA on table look-ups and address arithmetic for loads that go straight
 //     from L2 to registers, one load per (position, tap) item, nothing shared between the 8 waves of a workgroup;
 //   * with those gone, what is left is LOAD IMBALANCE: the row groups of a skeleton layer have K lengths between 18 and

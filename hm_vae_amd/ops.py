@@ -29,7 +29,7 @@ USE_V3 = _os.environ.get("HMVAE_V3", "1") != "0"
 WGRAD_PERSISTENT = _os.environ.get("HMVAE_WGRAD_PERSISTENT", "0") != "0"        # let the autotuner consider the v3 window kernel
 # Weight-gradient GEMM on the bf16 matrix pipe through exact three-way bf16 operand planes (hmvae.h, hmvae_wgrad_desc):
 # "0" never (default), "1" always, "auto" lets the autotuner time it against the fp32 MFMA per layer.  Measured on MI355X
-# (tools/wgrad_bf.py, B=256): fp32-grade results (4e-7 from the fp32 MFMA path) but 1.4x SLOWER -- the kernel streams every
+# (round-1 measurement, B=256): fp32-grade results (4e-7 from the fp32 MFMA path) but 1.4x SLOWER -- the kernel streams every
 # operand fragment from L2 per wave (~20 B/cycle/CU, its real ceiling), and the planes are 1.5x the bytes; the 2.7x
 # shorter MFMA time only pays once the operands are shared through LDS (what comes next).
 WGRAD_BF16X3 = _os.environ.get("HMVAE_WGRAD_BF16X3", "0")
@@ -105,7 +105,7 @@ def _tune_cache_put(key, val):
     with open(TUNE_CACHE, "w") as f:
         json.dump(_tune_cache, f)
 XCD_MODE = None if _os.environ.get("HMVAE_XCD") is None else int(_os.environ["HMVAE_XCD"])
-DEBUG_BUF = None          # diagnostic builds only (tools/stamp_gemm.py)
+DEBUG_BUF = None          # diagnostic builds only (-DHMVAE_STAMP: in-kernel s_memtime stamps)
 
 
 def pad_batch(b):
@@ -587,7 +587,7 @@ class MaskedGemm:
 
     def split_candidates(self, bp):
         """Splits of the (position, batch) reduction worth timing.  The grid is n_tiles * split workgroups of 4 waves and
-        its tail decides in a non-monotonic way (measured, tools/wgrad_split_sweep.py: 108 tiles run 57 / 35 / 51 / 41 us
+        its tail decides in a non-monotonic way (measured, tools/profile_layers.py with WG_SWEEP=1: 108 tiles run 57 / 35 / 51 / 41 us
         at split 1 / 2 / 3 / 4), so the whole small range is timed; the slab (split * tiles * 4 KB * mt) is capped."""
         kc = self._k_chunks(bp)
         per = (self.n_tiles_t * self.bwd.g.mt if self.wg_transposed else self.n_tiles * self.wg.mt) * 16 * 64 * 4

@@ -292,7 +292,7 @@ def build_items(pairs, np_):
 def pick_np_ksplit(mt, n_groups, n_pos, n_col_tiles, avg_nc4, target_waves=2048):
     """(64-column units per wave, K split over the waves of a workgroup) for the gather-GEMM.
 
-    Measured on MI355X (tools/sweep_gemm.py, B=256).  fp32 MFMA shares the SIMD's fp32 datapath with ordinary vector
+    Measured on MI355X (round 1, B=256).  fp32 MFMA shares the SIMD's fp32 datapath with ordinary vector
     instructions, so the more MFMAs a wave issues per item (mt*cw*4) the smaller the share lost to addressing; but
     the grid must still put a couple of waves on each of the 1024 SIMDs.
     """
