@@ -301,7 +301,10 @@ static int launch2(const hmvae_gemm2_desc* d, hipStream_t s) {
     const size_t lds = (TABLE_INTS + 3 * 2 * MAX_ITEMS) * sizeof(int) +
                        (d->ksplit > 1 ? (size_t)d->ksplit * MT * 16 * 64 * sizeof(float) : 0);
     // prefetch distance in items: short MFMA groups need more loads in flight per wave
-    constexpr int DEPTH = (MT * CW == 1) ? 4 : (MT * CW == 2 ? 3 : 2);
+#ifndef G2_DEPTH_BONUS
+#define G2_DEPTH_BONUS 0
+#endif
+    constexpr int DEPTH = ((MT * CW == 1) ? 4 : (MT * CW == 2 ? 3 : 2)) + G2_DEPTH_BONUS;
     hipLaunchKernelGGL((gather_gemm2_kernel<MT, CW, DEPTH>), grid, block, lds, s, *d);
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }

@@ -45,6 +45,7 @@ WGRAD_LDS = _os.environ.get("HMVAE_WGRAD_LDS", "auto")
 # significant cross terms run on the bf16 matrix pipe (csrc/wgrad_bf3.hip): fp32-grade sums at 3/8 of the fp32 MFMA issue
 # cycles.  A candidate of the autotuner unless HMVAE_WGRAD_BF3=0; HMVAE_WGRAD_LDS=2 forces it wherever it applies.
 WGRAD_BF3 = _os.environ.get("HMVAE_WGRAD_BF3", "1") != "0"
+GATHER_WPOS = _os.environ.get("HMVAE_GATHER_WPOS", "1") != "0"       # let the autotuner time the position-per-wave launch shape
 # the mode-2 GEMM writes the dense gradient from its own epilogue where the reduction is not split (no slab, no reduce launch)
 FUSE_WREDUCE = _os.environ.get("HMVAE_FUSE_WREDUCE", "1") != "0"
 LDS_BIAS = float(_os.environ.get("HMVAE_LDS_BIAS", "0.83"))
@@ -314,14 +315,20 @@ class _Side:
                                                       "x".join(map(str, self.strides)), bp)
 
     def v2_candidates(self, bp):
-        """(column units per wave, K split) pairs the v2 kernel accepts for this problem."""
+        """Launch shapes the v2 kernel accepts for this problem: (column units per wave, K split over the waves of a
+        workgroup), and (column units, 1, 4) = no K split, the four waves of a workgroup take four neighbouring output
+        positions -- four times the work per wave, a quarter of the workgroups and no cross-wave reduction: a gather
+        workgroup otherwise lives ~5 us, of which its table prologue and reduction epilogue are 2-3."""
         g = self.g
         out = []
         for cw in (1, 2, 4):
             if g.mt * cw > 4 or int(bp) % (64 * cw):
                 continue
+            # K splits with at least one 4-channel step per wave; tiny reductions (a 3-row head's transpose) get one wave
             for ks in ([ks for ks in (2, 4, 8) if float(g.g_nc4.mean()) / ks >= 1.0] or [1]):
                 out.append((cw, ks))
+            if GATHER_WPOS and self.n_pos >= 4:
+                out.append((cw, 1, 4))
         return out
 
     def autotune(self, src, dst, bp, bias, flags, slope):
@@ -341,26 +348,22 @@ class _Side:
         scratch = torch.empty_like(dst)
         fl = int(flags) & ~_lib.FLAG_ACCUM
         best = None
-        for cw in (1, 2, 4):
-            if g.mt * cw > 4 or int(bp) % (64 * cw):
-                continue
-            # K splits with at least one 4-channel step per wave; tiny reductions (a 3-row head's transpose) get one wave
-            ks_all = [ks for ks in (2, 4, 8) if float(g.g_nc4.mean()) / ks >= 1.0] or [1]
-            for ks in ks_all:
-                self.tune = (cw, ks)
-                t = self._time(lambda: self.run_v2(src, scratch, bp, bias, fl, slope))
-                if best is None or t < best[0]:
-                    best = (t, cw, ks)
+        for cand in self.v2_candidates(bp):
+            self.tune = cand
+            t = self._time(lambda: self.run_v2(src, scratch, bp, bias, fl, slope))
+            if best is None or t < best[0]:
+                best = (t, cand)
         self.tune = None
-        self._tuned_v2[bp] = (best[1], best[2])
-        pick = (best[1], best[2])
+        self._tuned_v2[bp] = best[1]
+        pick = best[1]
+        best = (best[0],) + tuple(best[1])
         if USE_V3 and self.n_pos >= 4 and g.kt > 1:
             for chunk, ts in ((8, 1), (4, 2)):
                 if self.window_plan(chunk, ts) is None:
                     continue
                 t = self._time(lambda: self.run_v3(src, scratch, bp, bias, fl, slope, chunk, ts))
                 if t < 0.97 * best[0]:
-                    best = (t, best[1], best[2])
+                    best = (t,) + tuple(best[1:])
                     pick = ("v3", chunk, ts, self._tuned_v2[bp][0], self._tuned_v2[bp][1])
             for key in [k for k in self._sched if k[0] == int(bp) and (pick[0] != "v3" or k[1:] != pick[1:3])]:
                 del self._sched[key]            # scratch tiles of the candidates that lost

@@ -78,6 +78,41 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("T,B,s", [(22, 130, 2), (16, 64, 1)])
+def test_gather_launch_shapes_agree(dev, T, B, s):
+    """Every launch shape the autotuner may pick for the v2 gather-GEMM -- (column units, K split) and the position-per-wave
+    shape (column units, 1, 4), incl. a last workgroup with fewer than four positions -- against the oracle's convolution,
+    forward and backward-data."""
+    from hm_vae_amd import ops
+    neigh = _level_neigh(0)
+    cin, cout, K = len(neigh) * 6, len(neigh) * 12, 15
+    mask = O.conv_mask(neigh, cin, cout, K)
+    g = torch.Generator().manual_seed(T)
+    w = (torch.randn(cout, cin, K, generator=g) * mask / 10.0).requires_grad_(True)
+    b = (0.1 * torch.randn(cout, generator=g)).requires_grad_(True)
+    x = torch.randn(B, cin, T, generator=g, requires_grad=True)
+    y = O.skel_conv(x, w, mask, b, s, 7, "reflect")
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    T_out = y.shape[2]
+    op = ops.conv_gemm(dev, neigh, cin, cout, K, s, 7, "reflect", T)
+    op.pack(w.detach().to(dev))
+    xs, bp = soa_from_bct(x.detach(), dev)
+    gys, _ = soa_from_bct(gy, dev)
+    shapes_f, shapes_b = op.fwd.v2_candidates(bp), op.bwd.v2_candidates(bp)
+    assert any(len(c) == 3 for c in shapes_f) and any(len(c) == 3 for c in shapes_b)
+    for cand in shapes_f:
+        op.fwd.tune = cand
+        ys = torch.full((cout * T_out, bp), float("nan"), device=dev)
+        op.fwd.run_v2(xs, ys, bp, b.detach().to(dev), 0, 0.2)
+        assert rel_err(bct_from_soa(ys, B, cout, T_out).numpy(), y.detach().numpy()) < TOL, cand
+    for cand in shapes_b:
+        op.bwd.tune = cand
+        dxs = torch.full((cin * T, bp), float("nan"), device=dev)
+        op.bwd.run_v2(gys, dxs, bp, None, 0, 0.2)
+        assert rel_err(bct_from_soa(dxs, B, cin, T).numpy(), x.grad.numpy()) < TOL, cand
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_skeleton_conv_fwd_bwd(dev, case):
     from hm_vae_amd import ops, _lib

@@ -7,10 +7,10 @@ kernels' (column units, K split), the weight-gradient GEMMs' (split, direct / LD
 re-captured and timed, a candidate is kept when it beats the incumbent by more than the measurement noise.  The result
 is written in the autotune-cache format (keys name shape and batch) and merged into the output file.
 
-Replaced graphs are parked, not destroyed (graph_step.retire: the destroy path corrupts the runtime's heap).  With many
-hundred parked graphs replays slow down (seen once: 1.81 -> 3.96 ms/step at the start of a second pass after ~700 graphs), so
-later candidates then only lose against the incumbent and the pass ends without changes: run one pass per process for big
-sweeps.  HMVAE_FORCE_SPLIT=1 tunes the four-graph DDP step: starting from the shipped choices it found < 1 % (1.825 ->
+On the HIP runtime bundled with the torch wheel (7.0.2) replaced graphs are parked, not destroyed (graph_step.py), and with
+many hundred parked graphs replays slow down (seen once: 1.81 -> 3.96 ms/step at the start of a second pass after ~700
+graphs).  Run the tuner on the image's 7.2.0 runtime instead, where graphs are destroyed normally:
+    LD_PRELOAD=/opt/rocm/lib/libamdhip64.so.7 python tools/tune_in_situ.py ...  HMVAE_FORCE_SPLIT=1 tunes the four-graph DDP step: starting from the shipped choices it found < 1 % (1.825 ->
 1.809 ms), so there is no separate file for it.
 """
 import argparse
@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--passes", type=int, default=2)
     ap.add_argument("--seq-len", type=int, default=0, help="override train_seq_len (trajectory model: config 5 quotes 64)")
+    ap.add_argument("--fast", action="store_true", help="weight-gradient splits 1, 2, 3, 4, 6, 8 only")
     ap.add_argument("--out", default=os.path.join(ROOT, "hm_vae_amd", "assets", "tune_mi355x.json"))
     a = ap.parse_args()
     import bench
@@ -95,6 +96,8 @@ def main():
     for ps in range(a.passes):
         improved = False
         for kind, obj in knobs:
+            base = measure()                 # the incumbent, re-timed: clocks drift over a run of several minutes
+            noise = 0.002 * base
             if kind == "g":
                 cur = tuple(obj._tuned[bp])
                 v2_now = tuple(obj._tuned_v2[bp])
@@ -126,8 +129,9 @@ def main():
                 label = obj.tune_key(bp)
             else:
                 cur = (obj._split_tuned[bp], obj._mode_tuned.get(bp, 0))
-                modes = [0, 1] if obj.lds_eligible() else [0]
-                cands = [(c, m) for m in modes for c in obj.split_candidates(bp) if (c, m) != cur]
+                modes = [0] + ([1] if obj.lds_eligible() else []) + ([2] if (ops.WGRAD_BF3 and obj.bf3_eligible()) else [])
+                splits = [c for c in obj.split_candidates(bp) if not a.fast or c in (1, 2, 3, 4, 6, 8)]
+                cands = [(c, m) for m in modes for c in splits if (c, m) != cur]
                 best_c, best_t = cur, base
                 for c, m in cands:
                     if VERBOSE:
