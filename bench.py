@@ -40,43 +40,71 @@ def synthetic_device_batch(B, T, seed, device):
 
 
 class KernelTimer:
-    """HIP-event timing of individual launches on the current stream (the stream the kernels are launched on)."""
+    """HIP-event timing of individual kernel launches: the events are recorded on the launch stream immediately around
+    the C-ABI call that launches the kernel (not around the Python that builds its descriptor), so an interval is the
+    kernel's own duration plus one launch gap."""
 
     def __init__(self):
         self.records = []
+        self.current = None            # (label, useful flops, issued flops) of the operator being launched
 
-    def wrap(self, obj, name, label, flops_fn):
+    def wrap_op(self, obj, name, label, flops_fn):
+        """Python-level: tags the launches made inside obj.name(...) with a family label and their flops."""
         orig = getattr(obj, name)
         timer = self
 
-        def timed(*a, **k):
+        def tagged(*a, **k):
+            fl = flops_fn(*a, **k)
+            timer.current = [label] + list(fl if isinstance(fl, tuple) else (fl, fl))
+            try:
+                return orig(*a, **k)
+            finally:
+                timer.current = None
+
+        setattr(obj, name, tagged)
+        return orig
+
+    def wrap_c(self, lib, name):
+        """C-ABI level: events around the launch itself; the flops of the operator are booked on its first launch."""
+        orig = getattr(lib, name)
+        timer = self
+
+        def timed(*a):
+            if timer.current is None:
+                return orig(*a)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            r = orig(*a, **k)
+            r = orig(*a)
             e1.record()
-            fl = flops_fn(*a, **k)
-            timer.records.append((label, e0, e1) + (fl if isinstance(fl, tuple) else (fl, fl)))
+            label, fl, issued = timer.current
+            timer.records.append((label, name, e0, e1, fl, issued))
+            timer.current[1] = timer.current[2] = 0.0
             return r
 
-        setattr(obj, name, timed)
+        setattr(lib, name, timed)
         return orig
 
     def summary(self):
         torch.cuda.synchronize()
-        agg = {}
-        for label, e0, e1, fl, issued in self.records:
+        agg, per_kernel = {}, {}
+        for label, cname, e0, e1, fl, issued in self.records:
             ms = e0.elapsed_time(e1)
             a = agg.setdefault(label, [0.0, 0.0, 0, 0.0])
             a[0] += ms
             a[1] += fl
             a[2] += 1
             a[3] += issued
+            k = per_kernel.setdefault(cname, [0.0, 0])
+            k[0] += ms
+            k[1] += 1
+        self.per_kernel = per_kernel
         return agg
 
 
 def instrument_gemms(engine, timer, bp):
-    """Wrap every MFMA launch of the engine; flops = mask-effective 2*MACs of that launch at this batch."""
-    from hm_vae_amd import ops
+    """Tag every MFMA operator of the engine (flops = mask-effective 2*MACs of that launch at this batch) and time the
+    launches behind them at the C ABI."""
+    from hm_vae_amd import _lib
     restore = []
     all_ops = engine.enc_conv + engine.dec_conv + engine.enc_lin + list(engine.dec_lin.values())
     fam = "gather_gemm (gather_gemm2_kernel | conv_window_kernel)"
@@ -86,10 +114,14 @@ def instrument_gemms(engine, timer, bp):
             if side is None:
                 continue
             issued = 2.0 * side.g.mfma_cost() * sum(len(l) for l in side.pairs_host)   # what the MFMAs execute
-            restore.append((side, "run", timer.wrap(side, "run", fam, lambda *a, _f=useful_f, _i=issued, **k:
-                                                    (_f * a[2], _i * a[2]) if len(a) > 2 else (0.0, 0.0))))
-        restore.append((op, "backward_weight", timer.wrap(op, "backward_weight", "wgrad (wgrad_kernel | wgrad_lds_kernel | wreduce_kernel)",
-                                                           lambda *a, _f=useful_f, **k: _f * a[3])))
+            restore.append((side, "run", timer.wrap_op(side, "run", fam, lambda *a, _f=useful_f, _i=issued, **k:
+                                                       (_f * a[2], _i * a[2]) if len(a) > 2 else (0.0, 0.0))))
+        restore.append((op, "backward_weight", timer.wrap_op(op, "backward_weight",
+                                                             "wgrad (wgrad_bf3_kernel | wgrad_lds_kernel | wgrad_kernel | wreduce_kernel)",
+                                                             lambda *a, _f=useful_f, **k: _f * a[3])))
+    lib = _lib.load()
+    for cname in ("hmvae_gather_gemm_v2", "hmvae_gather_gemm_v3", "hmvae_wgrad_gemm", "hmvae_wgrad_reduce"):
+        restore.append((lib, cname, timer.wrap_c(lib, cname)))
     return restore
 
 
@@ -450,13 +482,20 @@ def main():
                            "unit": "TFLOP/s", "frac": tfl / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                            "traffic_unit": "HBM-side bytes per launch (PMC)", "traffic_source": tsrc,
                            "launches_per_step": cnt // n_inst, "avg_launch_us": ms / cnt * 1e3,
+                           "timing": "HIP events on the launch stream around each C-ABI launch call of the family, %d extra "
+                                     "eager one-stream steps of the same workload" % n_inst,
+                           "per_entry_point": {k: {"ms_per_step": v[0] / n_inst, "launches_per_step": v[1] // n_inst}
+                                               for k, v in timer.per_kernel.items()},
                            "flops_per_step_effective": fl / n_inst,
                            "flops_per_step_issued": issued / n_inst,
                            "issued_TFLOP/s": issued / (ms * 1e-3) / 1e12,
                            "note": "achieved = algorithmic flops of the masked convolutions / kernel time; the MFMAs "
                                    "issue fewer flops than that where taps are folded (enc3, dec0) and more where 16-row "
                                    "tiles are padded: issued_TFLOP/s is what the matrix pipe executes",
-                           "all_kernels": {k: {"ms_per_step": v[0] / n_inst, "TFLOP/s": v[1] / (v[0] * 1e-3) / 1e12}
+                           "all_kernels": {k: {"ms_per_step": v[0] / n_inst, "TFLOP/s": v[1] / (v[0] * 1e-3) / 1e12,
+                                               "frac": v[1] / (v[0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                               "issued_TFLOP/s": v[3] / (v[0] * 1e-3) / 1e12,
+                                               "launches_per_step": v[2] // n_inst}
                                            for k, v in agg.items()}}
         conv_flops_step = 3.0 * eng.flops_per_seq * B
         out["roofline"]["step_level"] = {"conv_flops_per_step_effective": conv_flops_step,

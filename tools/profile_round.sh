@@ -5,10 +5,10 @@
 # eager launches (per-kernel times without two streams sharing the CUs), FETCH_SIZE, WRITE_SIZE (separate counter passes,
 # no other trace domains).  Outputs under gpurun_out/prof_TAG_*; tools/pmc_traffic.py turns them into
 # profiles/TAG_traffic.json and profiles/TAG_kernel_stats.csv.
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-fk --no-kernel-timing"
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-fk --no-kernel-timing --no-phase1"
 export HMVAE_TUNE_CACHE=$R/gpurun_out/tune_${TAG}.json
 rm -f $HMVAE_TUNE_CACHE
 python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_bench.json 2> $R/gpurun_out/prof_${TAG}_bench.err &&
