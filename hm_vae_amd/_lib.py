@@ -54,7 +54,7 @@ class WgradDesc(C.Structure):
                 ("pad", _i32), ("pad_mode", _i32), ("bp", _i32), ("dz_ts", _i32), ("x_ts", _i32), ("transposed", _i32),
                 ("items", _ptr), ("worker_items", _ptr), ("n_workers", _i32), ("mode", _i32),
                 ("dz_planes", _ptr), ("x_planes", _ptr), ("dz_plane_stride", _i64), ("x_plane_stride", _i64),
-                ("fused_reduce", _ptr)]
+                ("fused_reduce", _ptr), ("pair_tab", _ptr), ("n_pairs", _i32), ("pad2_", _i32)]
 
 
 class WreduceDesc(C.Structure):

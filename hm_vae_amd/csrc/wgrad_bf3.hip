@@ -62,12 +62,20 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& h0, unsigne
 
 __device__ __forceinline__ unsigned swz(unsigned row, unsigned slot) { return (slot ^ ((row >> 1) & 3u)) << 4; }
 
-template <int MT, int BP, bool ZP>
-__global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(hmvae_wgrad_desc d, int nch_max, int W, int WP, int WT, int brows) {
+// NH = 1: a workgroup (4 waves, two per CU) owns one 64-column tile.  NH = 2: a workgroup of 8 waves (one per CU) owns a
+// PAIR of neighbouring column tiles of one row group (desc.pair_tab): waves 0-3 multiply the first tile, waves 4-7 the
+// second, all 512 threads stage -- the gradient rows (the larger operand: every position needs its own) are loaded and
+// split once for 128 columns, i.e. half the bytes and half the vector instructions per MFMA for them.
+template <int MT, int BP, bool ZP, int NH>
+__global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad_bf3_kernel(hmvae_wgrad_desc d, int nch_max, int W, int WP,
+                                                                              int WT, int brows) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // layout: [utab: nch_max*WT u32][A planes 3 x AROWS x 64][B planes 3 x brows x 64]; afterwards the reduction buffer.
-    // BP counts the 32-row LOAD passes over the compact (channel, window row) index space; the image itself spaces the
-    // channels' windows WP rows apart (brows = nch_max * WP + one spare row that takes the slots past the tile's windows).
+    // BP counts the LOAD passes (THREADS / 8 rows each) over the compact (channel, window row) index space; the image
+    // itself spaces the channels' windows WP rows apart (brows = nch_max * WP + one spare row that takes the slots past the
+    // tile's windows).
+    constexpr int THREADS = 256 * NH;
+    constexpr int PROWS = THREADS / 8;                 // rows per load pass
     constexpr int AROWS = MT * 16 * TB;
     constexpr unsigned APL = AROWS * ROWB;
     const unsigned BPL = (unsigned)brows * ROWB;
@@ -76,14 +84,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(hmvae_wgrad_desc d, i
     char* bufA = lds + utab_bytes;
     char* bufB = bufA + 3 * APL;
 
+    const int n_units = NH == 2 ? d.n_pairs : d.n_tiles;          // what an item's first index counts
     int it0, it1;
-    if (d.n_workers > 0) {
+    if (NH == 1 && d.n_workers > 0) {
         const int perw = d.n_workers >> 3;
         const int worker = (blockIdx.x & 7) * perw + (blockIdx.x >> 3);
         it0 = d.worker_items[2 * worker];
         it1 = it0 + d.worker_items[2 * worker + 1];
     } else {
-        const int n_items = d.n_tiles * d.n_split;
+        const int n_items = n_units * d.n_split;
         const int per = (n_items + 7) >> 3;
         it0 = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
         if ((int)(blockIdx.x >> 3) >= per || it0 >= n_items) return;
@@ -91,40 +100,50 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(hmvae_wgrad_desc d, i
     }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pos = wave & 3;                  // this wave's position inside a stage
+    const int half = wave >> 2;                // ... and its column tile of the pair
     const int kk = lane >> 4;
     const int n = lane & 15;
     const int bp = d.bp;
     const int T = d.t_dst;
     const int q8 = threadIdx.x & 7;            // 16-byte piece of a 128-byte fp32 row = 8-byte piece of a 64-byte plane row
-    const int rr = threadIdx.x >> 3;           // row inside a pass of 32 rows
+    const int rr = threadIdx.x >> 3;           // row inside a load pass
 
     for (int item = it0; item < it1; ++item) {
-        int tile, lo, hi;
+        int tile, tile2 = -1, lo, hi, sp = 0;
         size_t part;
-        if (d.n_workers > 0) {
+        if (NH == 1 && d.n_workers > 0) {
             tile = d.items[4 * item];
             lo = d.items[4 * item + 1];
             hi = d.items[4 * item + 2];
             part = (size_t)d.items[4 * item + 3];
         } else {
-            tile = item / d.n_split;
-            const int sp = item - tile * d.n_split;
+            const int unit = item / d.n_split;
+            sp = item - unit * d.n_split;
             const long long total = (long long)T * (bp >> 5);
             lo = (int)(total * sp / d.n_split);
             hi = (int)(total * (sp + 1) / d.n_split);
+            if (NH == 2) {
+                tile = d.pair_tab[2 * unit];
+                tile2 = d.pair_tab[2 * unit + 1];              // -1: the group's last, unpaired tile
+            } else {
+                tile = unit;
+            }
             part = (size_t)sp * d.n_tiles + tile;
         }
+        const int my_tile = half ? tile2 : tile;               // wave-uniform; -1: nothing to multiply
         const int g = d.tile_g[tile];
-        const int col0 = d.tile_col0[tile];
+        const int col0 = d.tile_col0[tile];                    // the pair's second tile starts 64 columns later
         const int ncols = d.g_ncols[g];
         const int choff = d.g_choff[g];
         const int kt = d.kt;
         const int ch_lo = col0 / kt;
-        const int last_col = (col0 + 63 < ncols ? col0 + 63 : ncols - 1);
+        const int span = (NH == 2 && tile2 >= 0) ? 128 : 64;
+        const int last_col = (col0 + span - 1 < ncols ? col0 + span - 1 : ncols - 1);
         const int nch = last_col / kt - ch_lo + 1;            // <= nch_max (host)
 
         // utab[chl][i]: byte offset of channel chl's row at padded position i (source position i - pad), or ~0 = zero row
-        for (int i = threadIdx.x; i < nch * WT; i += 256) {
+        for (int i = threadIdx.x; i < nch * WT; i += THREADS) {
             const int chl = i / WT, v = i - chl * WT;
             const int xr = d.chan_rows[choff + ch_lo + chl];
             int u = v - d.pad;
@@ -138,17 +157,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(hmvae_wgrad_desc d, i
             }
             utab[i] = e;
         }
-        // this thread's rows of a stage: A passes (row index = pass*32 + rr over [p][r]), B passes (over [chl][v]).
+        // this thread's rows of a stage: A passes (row index = pass*PROWS + rr over [p][r]), B passes (over [chl][v]).
         // Every load, split and store of a stage is unconditional (dummy rows read row 0, slots past the windows go to the
         // spare row): a version that skipped them under per-lane conditions lost the overlap of the prefetch with the
         // MFMA block (the compiler waits for everything at the first branch) and ran 20 % slower.
-        constexpr int APASS = AROWS / 32;
+        constexpr int APASS = AROWS / PROWS;
         unsigned a_src[APASS];          // byte offset of row r at position 0, + piece: 32-bit, added to a uniform base
         int a_p[APASS];                 // position inside the stage
         unsigned a_lds[APASS];          // plane-0 byte address of this thread's 8-byte piece
 #pragma unroll
         for (int ps = 0; ps < APASS; ++ps) {
-            const int idx = ps * 32 + rr;
+            const int idx = ps * PROWS + rr;
             const int p = idx / (MT * 16), r = idx - p * (MT * 16);
             a_p[ps] = p;
             const int row = d.dz_rows[g * (MT * 16) + r];
@@ -160,42 +179,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(hmvae_wgrad_desc d, i
         const int utab_last = nch * WT - 1;
 #pragma unroll
         for (int ps = 0; ps < BP; ++ps) {
-            const int idx = ps * 32 + rr;
+            const int idx = ps * PROWS + rr;
             const int chl = idx / W, v = idx - chl * W;
             const bool in = idx < nch * W;
             b_u[ps] = in ? chl * WT + v : 0;
             const unsigned lrow = in ? (unsigned)(chl * WP + v) : (unsigned)(brows - 1);
             b_lds[ps] = lrow * ROWB + swz(lrow, (unsigned)q8 >> 1) + ((unsigned)q8 & 1u) * 8u;
         }
-        // fragment addresses: A row mt*16 + n of position `wave`; B column nt*16 + n -> (chl, tap)
+        // fragment addresses: A row mt*16 + n of position `pos`; B column nt*16 + n of this wave's tile -> (chl, tap)
         unsigned fa[MT], fb[4];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const unsigned ra = (unsigned)(wave * (MT * 16) + mt * 16 + n);
+            const unsigned ra = (unsigned)(pos * (MT * 16) + mt * 16 + n);
             fa[mt] = ra * ROWB + swz(ra, (unsigned)kk);
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            int col = col0 + nt * 16 + n;
+            int col = col0 + half * 64 + nt * 16 + n;
             col = col < ncols ? col : ncols - 1;                 // columns past the group's end are never read back
             const int ch = col / kt, tp = col - ch * kt;
-            const unsigned rb = (unsigned)((ch - ch_lo) * WP + wave * d.stride + tp);
+            const unsigned rb = (unsigned)((ch - ch_lo) * WP + pos * d.stride + tp);
             fb[nt] = rb * ROWB + swz(rb, (unsigned)kk);
         }
         const unsigned dz_tstep = (unsigned)d.dz_ts * (unsigned)bp * 4u;
         const char* __restrict__ dzb = (const char*)d.dz;
         const char* __restrict__ xb = (const char*)d.x;
-        // fused epilogue: this thread's column of the tile (channel, tap, mask pointer) and the ids / mask bytes of its
+        // fused epilogue: this thread's column of its tile (channel, tap, mask pointer) and the ids / mask bytes of its
         // rows are looked up NOW -- chains of dependent global loads that would otherwise sit exposed at the tile's end
+        const int e_tile = (threadIdx.x >> 8) ? tile2 : tile;  // the tile this thread writes in the epilogue
         WreduceCol wc = {};
         int e_rid[MT * 4];
         unsigned e_bits[MT * 4];
-        if (d.fused_reduce != nullptr) {
+        if (d.fused_reduce != nullptr && e_tile >= 0) {
             const hmvae_wreduce_desc& rd = *d.fused_reduce;
-            wc = wreduce_col(rd, tile, threadIdx.x & 63);
+            wc = wreduce_col(rd, e_tile, threadIdx.x & 63);
 #pragma unroll
             for (int i = 0; i < MT * 4; ++i) {
-                const int row = (threadIdx.x >> 6) + 4 * i;
+                const int row = ((threadIdx.x >> 6) & 3) + 4 * i;
                 e_rid[i] = rd.row_id[g * (MT * 16) + row];
                 e_bits[i] = wc.live ? wc.okp[row * wc.ok_stride] : 0u;
             }
@@ -260,9 +280,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(hmvae_wgrad_desc d, i
             if (s + 1 < s_hi) fetch(nbb, ntb);                    // in flight during the MFMA block below
             __builtin_amdgcn_sched_barrier(0);
             {
-                const int t = tb + wave;
+                const int t = tb + pos;
                 const int chunk = bb * T + t;
-                if (t < T && chunk >= lo && chunk < hi) {         // wave-uniform
+                if (my_tile >= 0 && t < T && chunk >= lo && chunk < hi) {         // wave-uniform
                     bf16x8 a[MT][3], b[4][3];
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) {
@@ -287,7 +307,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(hmvae_wgrad_desc d, i
             tb = ntb;
             __syncthreads();                                      // every wave has read its fragments: the image is free
         }
-        // cross-wave sum through LDS and the slab write: as in wgrad_kernel (the loop's last barrier has passed)
+        // cross-wave sum through LDS and the write-out (the loop's last barrier has passed): waves 0-3 hold the first
+        // tile's partial sums, waves 4-7 the second's; threads 0-255 / 256-511 finish the first / second tile
         float* red = (float*)lds;
         float* mine = red + wave * (MT * 16 * 64);
 #pragma unroll
@@ -297,30 +318,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(hmvae_wgrad_desc d, i
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mine[(mt * 16 + kk * 4 + r) * 64 + nt * 16 + n] = acc[mt][nt][r];
         __syncthreads();
-        if (d.fused_reduce != nullptr) {
-            // the tile goes straight into the dense gradient: thread = one column x 4 of every 16 rows (as wreduce_kernel,
-            // so a column's (channel, tap) split and mask pointer are computed once)
-            const hmvae_wreduce_desc& rd = *d.fused_reduce;
-            const int col = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+        const float* redh = red + (threadIdx.x >> 8) * (4 * MT * 16 * 64);
+        const int t256 = threadIdx.x & 255;
+        if (e_tile >= 0) {
+            if (d.fused_reduce != nullptr) {
+                // the tile goes straight into the dense gradient: thread = one column x 4 of every 16 rows (as
+                // wreduce_kernel, so a column's (channel, tap) split and mask pointer are computed once)
+                const hmvae_wreduce_desc& rd = *d.fused_reduce;
+                const int col = t256 & 63, r0 = t256 >> 6;
 #pragma unroll
-            for (int i = 0; i < MT * 4; ++i) {
-                const int row = r0 + 4 * i;
-                float sacc = red[row * 64 + col];
+                for (int i = 0; i < MT * 4; ++i) {
+                    const int row = r0 + 4 * i;
+                    float sacc = redh[row * 64 + col];
 #pragma unroll
-                for (int w = 1; w < 4; ++w) sacc += red[w * (MT * 16 * 64) + row * 64 + col];
-                wreduce_store(rd, wc, e_rid[i], e_bits[i], sacc);
-            }
-        } else {
-            const int rl = threadIdx.x >> 4;
-            const int cq = threadIdx.x & 15;
-            float* out = d.slab + part * (MT * 16 * 64);
+                    for (int w = 1; w < 4; ++w) sacc += redh[w * (MT * 16 * 64) + row * 64 + col];
+                    wreduce_store(rd, wc, e_rid[i], e_bits[i], sacc);
+                }
+            } else {
+                const int rl = t256 >> 4;
+                const int cq = t256 & 15;
+                float* out = d.slab + ((size_t)sp * d.n_tiles + e_tile) * (MT * 16 * 64);
+                if (NH == 1) out = d.slab + part * (MT * 16 * 64);               // (persistent launches number their parts)
 #pragma unroll
-            for (int ps = 0; ps < MT; ++ps) {
-                const int row = ps * 16 + rl;
-                f32x4 sacc = *(const f32x4*)(red + row * 64 + (cq << 2));
+                for (int ps = 0; ps < MT; ++ps) {
+                    const int row = ps * 16 + rl;
+                    f32x4 sacc = *(const f32x4*)(redh + row * 64 + (cq << 2));
 #pragma unroll
-                for (int w = 1; w < 4; ++w) sacc += *(const f32x4*)(red + w * (MT * 16 * 64) + row * 64 + (cq << 2));
-                *(f32x4*)(out + row * 64 + (cq << 2)) = sacc;
+                    for (int w = 1; w < 4; ++w) sacc += *(const f32x4*)(redh + w * (MT * 16 * 64) + row * 64 + (cq << 2));
+                    *(f32x4*)(out + row * 64 + (cq << 2)) = sacc;
+                }
             }
         }
         __syncthreads();
@@ -331,23 +357,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(hmvae_wgrad_desc d, i
 
 // Geometry shared with the host-side eligibility check (ops.py mirrors it): returns the LDS bytes, or 0 if unsupported.
 static size_t bf3_geometry(const hmvae_wgrad_desc* d, int* nch_max, int* W, int* WP, int* WT, int* BPs, int* brows) {
+    const bool pair = d->pair_tab != nullptr;
     if (d->transposed || d->dz_planes || d->kt < 2 || d->t_dst < TB || d->mt < 1 || d->mt > 4) return 0;
     if (d->fused_reduce && (d->n_split != 1 || d->n_workers != 0)) return 0;
-    *nch_max = 63 / d->kt + 2;
+    if (pair && (d->n_pairs <= 0 || d->n_workers != 0)) return 0;
+    *nch_max = (pair ? 127 : 63) / d->kt + 2;
     *W = (TB - 1) * d->stride + d->kt;
     *WP = d->kt;
     while (*WP < *W) *WP += 8;                                   // window pitch = kt (mod 8): see the header comment
     *WT = (d->t_dst - 1) * d->stride + d->kt;
     *brows = *nch_max * *WP + 1;                                 // + the spare row
-    const int bpass = (*nch_max * *W + 31) / 32;                 // load passes over the compact (chl, v) index space
+    const int prows = pair ? 64 : 32;
+    const int bpass = (*nch_max * *W + prows - 1) / prows;       // load passes over the compact (chl, v) index space
     if (bpass > 8) return 0;
     *BPs = bpass <= 4 ? 4 : (bpass <= 5 ? 5 : (bpass <= 6 ? 6 : 8));
     const size_t utab = (((size_t)*nch_max * *WT * 4 + 15) >> 4) << 4;
     const size_t stage = 3 * ((size_t)d->mt * 16 * TB + (size_t)*brows) * ROWB;
     size_t lds = utab + stage;
-    const size_t red = (size_t)4 * d->mt * 16 * 64 * sizeof(float);
+    const size_t red = (size_t)(pair ? 8 : 4) * d->mt * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
-    if (lds > 80 * 1024) return 0;                               // two workgroups per CU
+    if (lds > (pair ? 160 : 80) * 1024) return 0;                // two 4-wave workgroups per CU, or one of 8 waves
     return lds;
 }
 
@@ -357,21 +386,29 @@ int hmvae_wgrad_bf3_launch(const hmvae_wgrad_desc* d, unsigned grid, hipStream_t
     const size_t lds = bf3_geometry(d, &nch_max, &W, &WP, &WT, &BPs, &brows);
     if (!lds) return HMVAE_ERR_UNSUPPORTED;
     const bool zp = d->pad_mode == HMVAE_PAD_ZEROS;
-    static bool attr_set[5][9][2] = {};                    // dynamic LDS above 64 KB must be allowed once per kernel
-#define WL(MT_, BP_, ZP_)                                                                                               \
+    const bool pair = d->pair_tab != nullptr;
+    if (pair) {
+        const long long n_items = (long long)d->n_pairs * d->n_split;
+        grid = (unsigned)(((n_items + 7) / 8) * 8);
+    }
+    static bool attr_set[5][9][2][3] = {};                 // dynamic LDS above 64 KB must be allowed once per kernel
+#define WL(MT_, BP_, ZP_, NH_)                                                                                          \
     {                                                                                                                   \
-        if (!attr_set[MT_][BP_][ZP_]) {                                                                                 \
-            if (hipFuncSetAttribute((const void*)wgrad_bf3_kernel<MT_, BP_, ZP_>,                                       \
+        if (!attr_set[MT_][BP_][ZP_][NH_]) {                                                                            \
+            if (hipFuncSetAttribute((const void*)wgrad_bf3_kernel<MT_, BP_, ZP_, NH_>,                                  \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)              \
                 return HMVAE_ERR_LAUNCH;                                                                                \
-            attr_set[MT_][BP_][ZP_] = true;                                                                             \
+            attr_set[MT_][BP_][ZP_][NH_] = true;                                                                        \
         }                                                                                                               \
-        hipLaunchKernelGGL((wgrad_bf3_kernel<MT_, BP_, ZP_>), dim3(grid), dim3(256), lds, s, *d, nch_max, W, WP, WT,    \
-                           brows);                                                                                      \
+        hipLaunchKernelGGL((wgrad_bf3_kernel<MT_, BP_, ZP_, NH_>), dim3(grid), dim3(256 * NH_), lds, s, *d, nch_max, W, \
+                           WP, WT, brows);                                                                              \
     }
-#define WL_Z(MT_, BP_)      \
-    if (zp) WL(MT_, BP_, 1) \
-    else WL(MT_, BP_, 0)
+#define WL_N(MT_, BP_, ZP_)        \
+    if (pair) WL(MT_, BP_, ZP_, 2) \
+    else WL(MT_, BP_, ZP_, 1)
+#define WL_Z(MT_, BP_)        \
+    if (zp) WL_N(MT_, BP_, 1) \
+    else WL_N(MT_, BP_, 0)
 #define WL_B(MT_)                       \
     if (BPs == 4) { WL_Z(MT_, 4) }      \
     else if (BPs == 5) { WL_Z(MT_, 5) } \
@@ -386,6 +423,7 @@ int hmvae_wgrad_bf3_launch(const hmvae_wgrad_desc* d, unsigned grid, hipStream_t
     }
 #undef WL_B
 #undef WL_Z
+#undef WL_N
 #undef WL
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }

@@ -557,6 +557,7 @@ class MaskedGemm:
         self._bf_tuned = {}
         self._mode_tuned = {}
         self._fused = {}
+        self._pair_tab = None
         self._plane_buf = {}
         ge = self.geom
         if (self.bwd is not None and not self.folded and ge["stride"] == 1 and ge["pad_mode"] == _lib.PAD_REFLECT
@@ -609,21 +610,8 @@ class MaskedGemm:
         return (not self.wg_transposed) and self.kt >= 2 and ge["t_dst"] >= 4
 
     def bf3_eligible(self):
-        """Mirror of bf3_geometry (csrc/wgrad_bf3.hip): hmvae_wgrad_desc.mode = 2 supports this problem."""
-        ge = self.geom
-        mt = self.wg.mt
-        if not self.lds_eligible() or mt > 4:
-            return False
-        nch_max = 63 // self.kt + 2
-        W = 3 * ge["stride"] + self.kt
-        WP = self.kt
-        while WP < W:
-            WP += 8
-        WT = (ge["t_dst"] - 1) * ge["stride"] + self.kt
-        if (nch_max * W + 31) // 32 > 8:
-            return False
-        lds = (nch_max * WT * 4 + 15) // 16 * 16 + 3 * (mt * 16 * 4 + nch_max * WP + 1) * 64
-        return max(lds, 4 * mt * 16 * 64 * 4) <= 80 * 1024
+        """hmvae_wgrad_desc.mode = 2 supports this problem."""
+        return self._bf3_lds(False) is not None
 
     def wg_mode(self, bp):
         if not self.lds_eligible() or self.use_bf(bp):
@@ -632,7 +620,11 @@ class MaskedGemm:
             return int(WGRAD_LDS)
         if WGRAD_LDS == "2":
             return 2 if self.bf3_eligible() else 0
+        if WGRAD_LDS == "3":
+            return 3 if self.pair_eligible() else (2 if self.bf3_eligible() else 0)
         md = int(self._mode_tuned.get(bp, 0))
+        if md == 3:
+            return 3 if (WGRAD_BF3 and self.pair_eligible() and not self.persistent(bp)) else 0
         return md if (md < 2 or (WGRAD_BF3 and self.bf3_eligible())) else 0
 
     def use_bf(self, bp):
@@ -641,7 +633,47 @@ class MaskedGemm:
         return bool(self._bf_tuned.get(bp, False))
 
     def desc_mode(self, bp):
-        return self.wg_mode(bp)
+        """hmvae_wgrad_desc.mode of the launch: wg_mode 3 is mode 2 on tile pairs (desc.pair_tab)."""
+        md = self.wg_mode(bp)
+        return 2 if md == 3 else md
+
+    def _bf3_lds(self, pair):
+        """Mirror of bf3_geometry (csrc/wgrad_bf3.hip): LDS bytes of a mode-2 launch, or None if unsupported."""
+        ge = self.geom
+        mt = self.wg.mt
+        if not self.lds_eligible() or mt > 4:
+            return None
+        nch_max = (127 if pair else 63) // self.kt + 2
+        W = 3 * ge["stride"] + self.kt
+        WP = self.kt
+        while WP < W:
+            WP += 8
+        WT = (ge["t_dst"] - 1) * ge["stride"] + self.kt
+        prows = 64 if pair else 32
+        if (nch_max * W + prows - 1) // prows > 8:
+            return None
+        lds = (nch_max * WT * 4 + 15) // 16 * 16 + 3 * (mt * 16 * 4 + nch_max * WP + 1) * 64
+        lds = max(lds, (8 if pair else 4) * mt * 16 * 64 * 4)
+        return lds if lds <= (160 if pair else 80) * 1024 else None
+
+    def pair_eligible(self):
+        """Mode 2 on pairs of neighbouring column tiles (8-wave workgroups): worth it only where pairs exist."""
+        return self._bf3_lds(True) is not None and self.pair_tab()[1] < self.n_tiles
+
+    def pair_tab(self):
+        """(device table [n_pairs][2], n_pairs): consecutive 64-column tiles of one row group taken two at a time."""
+        if self._pair_tab is None:
+            tg, tc, _ = self.wg.wgrad_tiles()
+            pairs, t = [], 0
+            while t < len(tg):
+                if t + 1 < len(tg) and tg[t + 1] == tg[t] and tc[t + 1] == tc[t] + 64:
+                    pairs.append((t, t + 1))
+                    t += 2
+                else:
+                    pairs.append((t, -1))
+                    t += 1
+            self._pair_tab = (_dev(np.asarray(pairs, dtype=np.int32).reshape(-1), self.device), len(pairs))
+        return self._pair_tab
 
     def _planes(self, role, t):
         """The three bf16 planes of operand tensor `t` (split on the current stream into this op's scratch)."""
@@ -674,7 +706,7 @@ class MaskedGemm:
         # resident workgroups per CU by registers (VGPR + AGPR of the unified 512 per SIMD lane): mt 1 / 2 use 128 / 198,
         # mt 3 uses 268 and mt 4 333 -> one wave per SIMD (counted with rocprofv3: 838 of 1024 wave slots busy on average
         # for 1127 one-per-CU workgroups: the fifth round is 40 % empty)
-        per_cu = int(_os.environ.get("HMVAE_WG_PER_CU", "0")) or (2 if (mt <= 2 or self.wg_mode(bp) >= 1) else 1)
+        per_cu = int(_os.environ.get("HMVAE_WG_PER_CU", "0")) or (1 if self.wg_mode(bp) == 3 else (2 if (mt <= 2 or self.wg_mode(bp) >= 1) else 1))
         n_workers = max(8, (n_cu * per_cu) // 8 * 8)
         segs, wseg, _, _ = P.build_stream_schedule([kc] * n_tiles, [1] * n_tiles, n_workers, min_steps=2)
         items = np.zeros((max(len(segs), 1), 4), dtype=np.int32)
@@ -728,6 +760,8 @@ class MaskedGemm:
             modes.append((False, 1))
             if WGRAD_BF3 and self.bf3_eligible():
                 modes.append((False, 2))
+                if self.pair_eligible():
+                    modes.append((False, 3))
         for bf, md in modes:
             self._bf_tuned[bp] = bf
             self._mode_tuned[bp] = md
@@ -756,7 +790,7 @@ class MaskedGemm:
 
     def fusable(self, bp):
         """The launch can write the dense gradient from its epilogue (hmvae_wgrad_desc.fused_reduce)."""
-        return FUSE_WREDUCE and self.wg_mode(bp) == 2 and self.n_split(bp) == 1 and not self.persistent(bp)
+        return FUSE_WREDUCE and self.wg_mode(bp) in (2, 3) and self.n_split(bp) == 1 and not self.persistent(bp)
 
     def _fused_desc(self, slab, dw, bp, accumulate):
         """Device copy of the reduce descriptor for (slab, dw): made once per pointer set, outside any stream capture."""
@@ -815,7 +849,7 @@ class MaskedGemm:
                            _lib.ptr(self.g_ncols), _lib.ptr(tb["g_choff"]), _lib.ptr(self.wg_chan_rows),
                            _lib.ptr(self.dz_rows), self.n_tiles, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"],
                            ge["stride"], ge["pad"], ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 0, *self._wg_items(bp),
-                           *self._plane_args(dy, x, bp), fused)
+                           *self._plane_args(dy, x, bp), fused, *self._pair_args(bp))
         _lib.check(lib.hmvae_wgrad_gemm(C.byref(d), _lib.stream()), "wgrad_gemm")
         return fused is not None
 
@@ -824,6 +858,12 @@ class MaskedGemm:
             return (None, None, 0, self.desc_mode(bp))
         sc = self.wg_schedule(bp)
         return (_lib.ptr(sc["items"]), _lib.ptr(sc["worker_items"]), sc["n_workers"], self.desc_mode(bp))
+
+    def _pair_args(self, bp):
+        if self.wg_mode(bp) != 3:
+            return (None, 0, 0)
+        tab, n = self.pair_tab()
+        return (_lib.ptr(tab), n, 0)
 
     def _wg_parts(self, bp):
         if not self.persistent(bp):
@@ -843,7 +883,7 @@ def _mg_wgrad_gemm_t(self, dy, x, bp, slab):
     d = _lib.WgradDesc(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(slab), _lib.ptr(self.tile_g_t), _lib.ptr(self.tile_col0_t),
                        _lib.ptr(self.g_ncols_t), _lib.ptr(b.g_choff), _lib.ptr(b.chan_rows), _lib.ptr(b.dst_rows),
                        self.n_tiles_t, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"], ge["stride"], ge["pad"],
-                       ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 1, *self._wg_items(bp), *self._plane_args(dy, x, bp), None)
+                       ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 1, *self._wg_items(bp), *self._plane_args(dy, x, bp), None, None, 0, 0)
     _lib.check(lib.hmvae_wgrad_gemm(C.byref(d), _lib.stream()), "wgrad_gemm(T)")
 
 

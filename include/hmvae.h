@@ -203,6 +203,12 @@ typedef struct {
      * MEMORY.  The GEMM's epilogue then writes every tile straight into the dense gradient (mask, deduplicated children,
      * accumulate: exactly what hmvae_wgrad_reduce does) -- no slab traffic, no reduce launch.  NULL: write the slab. */
     const struct hmvae_wreduce_desc_s* fused_reduce;
+    /* Optional, mode 2, n_workers == 0: the tiles taken two at a time.  pair_tab[2i], pair_tab[2i+1] = a tile and the next
+     * 64-column tile of the SAME row group (or -1 for a group's last, unpaired tile), n_pairs entries; a workgroup of 8
+     * waves then owns the pair and stages the gradient rows once for both.  Slab layout and reduce are unchanged. */
+    const int32_t* pair_tab;
+    int32_t n_pairs;
+    int32_t pad2_;
 } hmvae_wgrad_desc;
 
 int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream);

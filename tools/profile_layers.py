@@ -52,21 +52,11 @@ for name, op in zip(names, convs):
         op.n_tiles, op.wg.mt, op._split_tuned.get(bp), op.wg_mode(bp), t_w, t_g, useful/t_w/1e6, issued_w/t_g/1e6)
     print(line)
     if os.environ.get("WG_SWEEP"):
-        for md in (0, 1, 2):
-            if (md == 1 and not op.lds_eligible()) or (md >= 2 and not op.bf3_eligible()):
+        for md in (0, 1, 2, 3):
+            if (md == 1 and not op.lds_eligible()) or (md == 2 and not op.bf3_eligible()) or (md == 3 and not op.pair_eligible()):
                 continue
             for sp in op.split_candidates(bp):
                 op._mode_tuned[bp], op._split_tuned[bp] = md, sp
-                if md == 3:      # the kernel alone on planes made once; the split pass is timed on its own below
-                    xw, dyw = x[:rows_x - 400000] if op.folded else x, dy[:rows_y - 400000] if op.folded else dy
-                    args = op._plane_args(dyw, xw, bp)
-                    real = op._plane_args
-                    op._plane_args = lambda *a, _v=args: _v
-                    t_k = timeit(lambda: op.wgrad_gemm(dy, x, bp, slab), reps=8)
-                    op._plane_args = real
-                    t_s = timeit(lambda: real(dyw, xw, bp), reps=8)
-                    print("      mode 3 split %2d: kernel %7.1f us  + plane split %6.1f us   %5.1f TF issued (kernel)" % (sp, t_k, t_s, issued_w/t_k/1e6))
-                    continue
                 t_g = timeit(lambda: op.wgrad_gemm(dy, x, bp, slab), reps=8)
                 t_w = timeit(lambda: op.backward_weight(dy, x, dw, bp, slab), reps=8)
                 print("      mode %d split %2d: gemm %7.1f us  gemm+reduce %7.1f us  %5.1f TF issued" % (md, sp, t_g, t_w, issued_w/t_g/1e6))
