@@ -113,6 +113,10 @@ class LatentRefiner:
             names += ["dec.latent_dec_layers.%d.weight" % i, "dec.latent_dec_layers.%d.bias" % i]
         return names
 
+    def _dead_heads(self):
+        L = self.eng.p.L
+        return ["dec.latent_dec_layers.%d.%s" % (i, s) for i in range(1, L - 1) for s in ("weight", "bias")]
+
     # ------------------------------------------------------------------------------------------
     def loss_and_grads(self, decoder_phase):
         """One forward + backward.  Leaves d l_total / d z in z_*.grad and (decoder_phase) d l_total / d decoder tensors in
@@ -147,6 +151,9 @@ class LatentRefiner:
         reg_dec = float(hp.get("reg_w_decoder", 0.0)) if self.optimize_decoder else 0.0
         if self.optimize_decoder and (decoder_phase or self._decoder_moved):
             # (before the first decoder update every term is exactly zero -- p == p_original -- and DREGP still holds zeros)
+            if decoder_phase:
+                for name in self._dead_heads():       # no kernel writes their gradient: the regulariser's term is all of it
+                    eng.grad_view(name).zero_()
             for k, name in enumerate(self._decoder_names()):
                 t = eng.params[name]
                 n = t.numel()

@@ -96,8 +96,12 @@ def test_trainer_step_on_device_dataset(dev, tmp_path):
     cfg = load_cfg("len8")
     cfg["batch_size"] = 3
     assert cfg["fps_aug_flag"] and cfg["random_root_rot_flag"]
+    import json
+    from hm_vae_amd.utils_motion_vae import TRAIN_IDS, VAL_IDS
+    json.dump({str(i): "m%d.npy" % i for i in range(6)}, open(os.path.join(str(tmp_path), TRAIN_IDS), "w"))
+    json.dump({"0": "m4.npy", "1": "m5.npy", "2": "m0.npy"}, open(os.path.join(str(tmp_path), VAL_IDS), "w"))
     tr_ld, va_ld, te_ld = get_train_loaders_all_data_seq(cfg, dev, str(tmp_path))
-    assert len(tr_ld) == 2 and te_ld.B == 1 and tr_ld.fps_aug and tr_ld.root_rot
+    assert len(tr_ld) == 2 and len(va_ld) == 1 and te_ld.ds is va_ld.ds and tr_ld.fps_aug and tr_ld.root_rot
     tr = Trainer(cfg)
     tr.cuda()
     for it, batch in enumerate(tr_ld):
