@@ -121,6 +121,24 @@ class HipAdam(torch.optim.Adam):
             ent['step'].fill_(ent['host'])
             ent['live'] = all(p.grad is not None for p in ent['params'])
 
+    def reset_state(self):
+        """Back to "never stepped" without touching a pointer: moments zeroed in place, host and device step counters 0,
+        learning rates back to their initial values.  Captured graphs that address this optimiser's tables stay valid --
+        this is what lets one refinement context (and its two graphs) serve window after window."""
+        for p, st in self.state.items():
+            if len(st):
+                st['exp_avg'].zero_()
+                st['exp_avg_sq'].zero_()
+                st['step'] = torch.tensor(0.0)
+                self._host_step[p] = 0
+        for ent in self._cache.values():
+            ent['host'] = 0
+            ent['step'].fill_(0)
+        for group in self.param_groups:
+            if 'initial_lr' in group:
+                group['lr'] = group['initial_lr']
+        self.sync_lr()
+
     def state_dict(self):
         for p, n in self._host_step.items():
             if p in self.state and len(self.state[p]):

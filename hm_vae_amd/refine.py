@@ -38,60 +38,82 @@ class LatentRefiner:
         self.model, self.hp = model, hp
         # an iteration is ~35 (latent phase) / ~75 (decoder phase) launches of a few microseconds each at the reference's
         # batch of one window: replayed from a hipGraph per phase (the phase's first iteration runs eagerly -- it creates
-        # the optimiser's tables -- the second is captured)
+        # the optimiser's tables -- the second is captured).  Everything a graph addresses (latents, Adam state, targets,
+        # mask, anchor) lives for the refiner's lifetime; begin() loads a new window into the same buffers, so ONE refiner
+        # and its two graphs serve every window batch of the same shape (TwoHierSAVAEModel.refine_window keeps them).
         self.use_graph = (os.environ.get("HMVAE_REFINE_GRAPH", "1") != "0") if use_graph is None else bool(use_graph)
         self._graphs, self._eager_done = {}, {False: 0, True: 0}
         self.eng = eng = model.engine()
         p, dev = eng.p, eng.device
         if hp.get('optimize_trajectory', False):
             raise NotImplementedError("optimize_trajectory (seq_two_hier_sa_vae.py:1376-1386) is not built")
-        R = target_rot_mat.to(device=dev, dtype=torch.float32).contiguous()
-        B, T = R.shape[0], R.shape[1]
+        B, T = target_rot_mat.shape[0], target_rot_mat.shape[1]
         if T != p.T:
             raise ValueError("window length %d != train_seq_len %d" % (T, p.T))
-        if tuple(mask.shape) != (B, T, 24):
-            raise ValueError("mask must be (B, T, 24)")
         self.B, self.T = B, T
         self.w = w = eng.workspace(B)
         bp = w["bp"]
-        # targets: 6D = the first two columns of R (:1279-1280), R, joint positions by FK (:1282)
-        r6 = torch.stack((R[..., 0], R[..., 1]), dim=-2).reshape(B, T, 144).contiguous()
-        eng.stage_batch(w, r6, R.reshape(B, T, 216))
         if "MK" not in w:
             w["MK"] = torch.zeros(24 * T, bp, device=dev)
             nb = ops.l2_anchor_blocks()
             w["REGP"] = torch.zeros(2 * nb, device=dev)
             w["DREGP"] = torch.zeros(max(1, len(self._decoder_names())) * nb, device=dev)
             w["ZERO1"] = torch.zeros(1, device=dev)
-        ops.aos_to_soa(mask.to(device=dev, dtype=torch.float32).contiguous(), w["MK"], B, T, 24, bp)
         L = p.L
         k0, d0, kd, dd = p.edge_num[1], p.lat_dim[0], p.edge_num[L], p.lat_dim[L - 1]
-        if z_shallow is None:                         # :1317-1318: the deep code first, then the shallow one
-            z_deep = torch.randn(B, kd, dd, device=dev)
-            z_shallow = torch.randn(B, k0, d0, device=dev)
-        self.z_shallow = torch.nn.Parameter(z_shallow.to(device=dev, dtype=torch.float32).clone().contiguous())
-        self.z_deep = torch.nn.Parameter(z_deep.to(device=dev, dtype=torch.float32).clone().contiguous())
+        self.z_shallow = torch.nn.Parameter(torch.zeros(B, k0, d0, device=dev))
+        self.z_deep = torch.nn.Parameter(torch.zeros(B, kd, dd, device=dev))
         self.z_shallow.grad = torch.zeros_like(self.z_shallow)
         self.z_deep.grad = torch.zeros_like(self.z_deep)
         self.gen_opt = HipAdam([self.z_shallow, self.z_deep], lr=hp['opt_lr'], weight_decay=hp['weight_decay'])
-        self.gen_scheduler = get_opt_scheduler(self.gen_opt, hp)
         self.optimize_decoder = bool(hp.get('optimize_decoder', False))
         self.anchor = None
+        self.gen_opt_for_decoder = None
         if self.optimize_decoder:
             names = self._decoder_names()
             self.anchor = {n: eng.params[n].detach().clone() for n in names}
             eng.grad_layout()
-            for n in names:
-                eng.params[n].grad = eng.grad_view(n)
             self.gen_opt_for_decoder = HipAdam([eng.params[n] for n in names], lr=hp['opt_lr'] * 0.001,
                                                weight_decay=hp['weight_decay'])
+        self.losses = torch.zeros(8, device=dev)
+        self.begin(target_rot_mat, mask, z_shallow, z_deep)
+
+    def begin(self, target_rot_mat, mask, z_shallow=None, z_deep=None):
+        """Load a window batch (same shape as the refiner was built for) and start over: iteration 0, fresh Adam state,
+        the anchor = the model's current decoder.  No buffer a captured graph addresses is replaced."""
+        eng, w, hp = self.eng, self.w, self.hp
+        p, dev, B, T, bp = eng.p, eng.device, self.B, self.T, self.w["bp"]
+        R = target_rot_mat.to(device=dev, dtype=torch.float32).contiguous()
+        if tuple(R.shape[:2]) != (B, T) or tuple(mask.shape) != (B, T, 24):
+            raise ValueError("this refiner serves windows of shape (%d, %d, 24, 3, 3) with a (B, T, 24) mask" % (B, T))
+        # targets: 6D = the first two columns of R (:1279-1280), R, joint positions by FK (:1282)
+        r6 = torch.stack((R[..., 0], R[..., 1]), dim=-2).reshape(B, T, 144).contiguous()
+        eng.stage_batch(w, r6, R.reshape(B, T, 216))
+        ops.aos_to_soa(mask.to(device=dev, dtype=torch.float32).contiguous(), w["MK"], B, T, 24, bp)
+        with torch.no_grad():
+            if z_shallow is None:                     # :1317-1318: the deep code first, then the shallow one
+                z_deep = torch.randn(self.z_deep.shape, device=dev)
+                z_shallow = torch.randn(self.z_shallow.shape, device=dev)
+            self.z_shallow.copy_(z_shallow.to(device=dev, dtype=torch.float32))
+            self.z_deep.copy_(z_deep.to(device=dev, dtype=torch.float32))
+        self.z_shallow.grad.zero_()
+        self.z_deep.grad.zero_()
+        self.gen_opt.reset_state()
+        self.gen_scheduler = get_opt_scheduler(self.gen_opt, hp)
+        if self.optimize_decoder:
+            with torch.no_grad():
+                for n, t in self.anchor.items():
+                    t.copy_(eng.params[n])
+            for n in self.anchor:
+                eng.params[n].grad = eng.grad_view(n)
+            self.gen_opt_for_decoder.reset_state()
             self.gen_scheduler_for_decoder = get_opt_scheduler(self.gen_opt_for_decoder, hp)
         self.it = 0
-        self._packed = False
+        eng.pack_decoder()                            # (the latent phase's captured iteration does not pack)
+        self._packed = True
         self._decoder_moved = False
-        if "DREGP" in w:
-            w["DREGP"].zero_()
-        self.losses = torch.zeros(8, device=dev)
+        w["DREGP"].zero_()
+        self._restored = False
 
     def _decoder_names(self):
         """The trainable tensors of `dec` proper: the convolutions and ALL latent heads.  The two middle heads feed nothing
@@ -229,8 +251,7 @@ class LatentRefiner:
                 for n, t in self.anchor.items():
                     self.eng.params[n].copy_(t)
             self.eng.pack_decoder()
-        graph_step.retire(*self._graphs.values())       # parked, not destroyed (graph_step.py)
-        self._graphs = {}
+        self._restored = True                          # the graphs stay: begin() reuses them for the next window
 
 
 def temporal_mask(T, window):

@@ -275,7 +275,17 @@ class TwoHierSAVAEModel(nn.Module):
         a batch of windows: target_rot_mat (B,T,24,3,3), mask (B,T,24).  Returns (cont6d, R, pos, loss history (it, 8));
         the decoder is restored afterwards, as the reference optimises a deep copy."""
         from .refine import LatentRefiner
-        ref = LatentRefiner(self, self.hp if hp is None else hp, target_rot_mat, mask, z_shallow, z_deep)
+        hp = self.hp if hp is None else hp
+        # one refiner (buffers, optimisers, two captured graphs) per window shape and set of hyper-parameters, reused
+        # window after window: the graphs bake the scalars in, so the key holds every scalar of hp
+        key = (int(target_rot_mat.shape[0]), int(target_rot_mat.shape[1]),
+               tuple(sorted((k, v) for k, v in hp.items() if isinstance(v, (int, float, bool, str)))))
+        cache = self.__dict__.setdefault("_refiners", {})
+        ref = cache.get(key)
+        if ref is None or ref.eng is not self.engine():
+            ref = cache[key] = LatentRefiner(self, hp, target_rot_mat, mask, z_shallow, z_deep)
+        else:
+            ref.begin(target_rot_mat, mask, z_shallow, z_deep)
         try:
             hist = ref.run(iterations)
             c6, R, pos = ref.decode()

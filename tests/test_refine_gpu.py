@@ -240,6 +240,34 @@ def test_full_loop_interpolates_and_restores(dev):
     assert per_frame.shape == (B, T) and float(l) >= 0
 
 
+def test_one_refiner_serves_window_after_window(dev):
+    """TwoHierSAVAEModel.refine_window keeps ONE refiner (buffers, optimisers, two captured graphs) per window shape: a
+    second and third window replay the same graphs from iteration 0, and the state is fully reset in between -- window A
+    run again after window B repeats its first run."""
+    from hm_vae_amd import graph_step
+    cfg = interp_cfg()
+    cfg["opt_it"] = 60                                # 51 latent + 9 decoder iterations
+    model, plan, seeded = make_model(cfg, dev)
+    B, T = 2, cfg["train_seq_len"]
+    wins = [(smooth_rotations(B, T, 41 + k), joint_mask(B, T, cfg["interpolation_window"], 51 + k)) for k in range(2)]
+    g = torch.Generator().manual_seed(61)
+    z = [(torch.randn(B, plan.edge_num[1], plan.lat_dim[0], generator=g),
+          torch.randn(B, plan.edge_num[plan.L], plan.lat_dim[plan.L - 1], generator=g)) for _ in range(2)]
+    runs = []
+    parked = len(graph_step._RETIRED)
+    for k in (0, 1, 0):
+        c6, R, pos, hist = model.refine_window(wins[k][0], wins[k][1], z_shallow=z[k][0], z_deep=z[k][1])
+        runs.append((hist.copy(), pos.cpu().numpy().copy()))
+        for n, t in model.engine().params.items():    # decoder restored bit for bit after every window
+            if n in seeded:
+                assert torch.equal(t.detach().cpu(), seeded[n]), n
+    assert len(model._refiners) == 1
+    ref = next(iter(model._refiners.values()))
+    assert len(ref._graphs) == 2 and len(graph_step._RETIRED) == parked        # two captures in all, nothing retired
+    assert rel_err(runs[2][0], runs[0][0]) < 1e-6 and rel_err(runs[2][1], runs[0][1]) < 1e-6
+    assert rel_err(runs[1][0][:, 0], runs[0][0][:, 0]) > 1e-3                  # (window B really is another problem)
+
+
 def test_graph_replay_equals_eager(dev, monkeypatch):
     """The per-phase hipGraph replay runs the same launches as the eager loop: same loss history, same result."""
     from hm_vae_amd import graph_step, refine
