@@ -36,6 +36,15 @@ class Gemm2Desc(C.Structure):
                 ("dst_ts", _i32), ("flags", _i32), ("slope", _f32), ("debug", _ptr), ("bias_idx2", _ptr)]
 
 
+class Gemm4Desc(C.Structure):
+    _fields_ = [("src", _ptr), ("dst", _ptr), ("wp4", _ptr), ("bias", _ptr), ("bias_idx", _ptr), ("bias_idx2", _ptr),
+                ("g_nc32", _ptr), ("g_woff4", _ptr), ("g_choff", _ptr), ("g_ntiles", _ptr), ("chan_rows", _ptr),
+                ("dst_rows", _ptr), ("pb_off", _ptr), ("pb_len", _ptr), ("items", _ptr), ("scratch", _ptr),
+                ("counters", _ptr), ("n_groups", _i32), ("mtw", _i32), ("nc", _i32), ("kt", _i32), ("n_pos", _i32),
+                ("bp", _i32), ("n_split", _i32), ("n_units", _i32), ("max_items", _i32), ("max_nc32", _i32),
+                ("src_ts", _i32), ("dst_ts", _i32), ("flags", _i32), ("slope", _f32)]
+
+
 class Conv3Desc(C.Structure):
     _fields_ = [("src", _ptr), ("dst", _ptr), ("wp", _ptr), ("bias", _ptr), ("bias_idx", _ptr),
                 ("chan_rows", _ptr), ("dst_rows", _ptr),
@@ -96,6 +105,7 @@ _SIGS = {
     "hmvae_gather_gemm": ([C.POINTER(GemmDesc), _ptr], _i32),
     "hmvae_gather_gemm_v2": ([C.POINTER(Gemm2Desc), _ptr], _i32),
     "hmvae_gather_gemm_v3": ([C.POINTER(Conv3Desc), _ptr], _i32),
+    "hmvae_gather_gemm_v4": ([C.POINTER(Gemm4Desc), _ptr], _i32),
     "hmvae_wgrad_gemm": ([C.POINTER(WgradDesc), _ptr], _i32),
     "hmvae_wgrad_reduce": ([C.POINTER(WreduceDesc), _ptr], _i32),
     "hmvae_pack_weights": ([_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
@@ -103,6 +113,7 @@ _SIGS = {
     "hmvae_row_sums_scaled": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_row_sums_multi": ([_ptr, _i32, _i32, _ptr], _i32),
     "hmvae_pack_weights_multi": ([_ptr, _i32, _i32, _i32, _ptr], _i32),
+    "hmvae_pack_weights_v4": ([_ptr, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_pool_leaky_fwd": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),
     "hmvae_pool_leaky_bwd": ([_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),
     "hmvae_upsample_unpool_fwd": ([_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),

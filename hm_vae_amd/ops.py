@@ -20,6 +20,10 @@ USE_V2 = _os.environ.get("HMVAE_GEMM", "v2") != "v1"
 AUTOTUNE = _os.environ.get("HMVAE_AUTOTUNE", "1") != "0"
 FOLD = _os.environ.get("HMVAE_FOLD", "1") != "0"        # tap folding for convolutions over fewer positions than taps
 USE_V3 = _os.environ.get("HMVAE_V3", "1") != "0"
+# Fourth-generation gather-GEMM (csrc/gemm_v4.hip): three bf16 planes per operand on the bf16 matrix pipe, fp32-grade
+# results.  "auto" (default): timed per layer side and batch size against the v2 / v3 pick; "0" never; "1" wherever the
+# kernel supports the problem (first candidate shape).
+USE_V4 = _os.environ.get("HMVAE_V4", "auto")
 # Let the autotuner consider the persistent (stream-K) weight-gradient launch.  Off by default: timed alone it wins on
 # most layers, but in the step these GEMMs share the chip with the data-gradient chain and with each other, and workers
 # that hold every CU for their whole launch cost the neighbours more than the balanced tail saves.  A/B on the whole step,
@@ -121,9 +125,18 @@ class _Side:
     """One gather-GEMM direction: groups + position pairs + row maps (all on the device)."""
 
     def __init__(self, device, groups, pairs, chan_row_base, row_dst_base, bias_rows, src_ts, dst_ts, dense_strides,
-                 fold=None, bias_rows2=None):
+                 fold=None, bias_rows2=None, groups4=None, layout=2):
         self.g = groups
         self.device = device
+        self.layout = int(layout)             # 2: fp32 fragments of the v2 / v3 kernels; 4: bf16 planes of the v4 kernel
+        # companions in the v4 layout, keyed by row tiles per wave (their groups hold 64 / 128 rows); made on demand
+        self.v4 = {}
+        self._v4_args = None
+        if layout == 2 and groups4 is not None and USE_V4 != "0":
+            self._v4_args = (groups4, pairs, chan_row_base, row_dst_base, bias_rows, src_ts, dst_ts, dense_strides, fold,
+                             bias_rows2)
+        self._last_dense = None
+        self._tuned_v4 = {}
         # fold = dict(taps [kt][nf], coefs [kt][nf], kt_real, child_tab [n][4] or None, child_side): the packed matrix is a
         # composite one (virtual taps, merged channels; hmvae.h, hmvae_pack_op)
         self.fold = None
@@ -173,7 +186,32 @@ class _Side:
         self.p_off, self.p_len, self.pairs = _dev(p_off, device), _dev(p_len, device), _dev(flat, device)
         self.src_ts, self.dst_ts = int(src_ts), int(dst_ts)
         self.strides = tuple(int(s) for s in dense_strides)       # (row_stride, chan_stride, tap_stride)
-        self.wp = torch.zeros(max(groups.packed_size, 1), dtype=torch.float32, device=device)
+        if self.layout == 4:
+            g = groups
+            assert (g.g_nc4 % 8 == 0).all()
+            self.g_nc32 = _dev((g.g_nc4 // 8).astype(np.int32), device)
+            frags = (g.g_nc4 // 8).astype(np.int64) * g.kt * g.mt * 3
+            woff4 = np.concatenate([[0], np.cumsum(frags)[:-1]]).astype(np.int64)
+            assert int(frags.sum()) * 1024 < 2 ** 31
+            self.g_woff4 = _dev(woff4.astype(np.int32), device)
+            ntl = [max(1, -(-int((groups.row_id.reshape(g.n_groups, -1)[gi] >= 0).sum()) // 16)) for gi in range(g.n_groups)]
+            self.g_ntiles = _dev(np.asarray(ntl, dtype=np.int32), device)
+            self.wp = torch.zeros(max(int(frags.sum()) * 512, 1), dtype=torch.int16, device=device)
+            self._v4_scratch = {}
+        else:
+            self.wp = torch.zeros(max(groups.packed_size, 1), dtype=torch.float32, device=device)
+
+    def v4_side(self, mtw):
+        """The companion side in the v4 layout with 4*mtw row tiles per group (None if the problem is not supported)."""
+        if self._v4_args is None:
+            return None
+        if mtw not in self.v4:
+            make, pairs, *rest = self._v4_args
+            g4 = make(64 * mtw)
+            n_items = max(len(l) for l in pairs)
+            ok = g4 is not None and int(g4.g_nc4.max()) // 8 <= 32 and n_items <= 256
+            self.v4[mtw] = _Side(self.device, g4, pairs, *rest, layout=4) if ok else None
+        return self.v4[mtw]
 
     def pack(self, dense):
         MultiPack(self.device).run([(self, dense)])
@@ -183,6 +221,17 @@ class _Side:
         g = self.g
         rs, cs, ts = self.strides
         f = self.fold
+        self._last_dense = dense
+        if self.layout == 4:
+            return _lib.PackOp(_lib.ptr(dense), self.wp.data_ptr(), _lib.ptr(self.g_nc4), _lib.ptr(self.g_woff4),
+                               _lib.ptr(self.g_choff), _lib.ptr(self.chan_id), _lib.ptr(self.row_id), _lib.ptr(self.g_okoff),
+                               _lib.ptr(self.pair_ok), g.n_groups, int(g.g_nc4.max()), g.mt, g.kt, rs, cs, ts, int(block_start),
+                               0, None if f is None else _lib.ptr(f["taps"]),
+                               None if f is None else _lib.ptr(f["coefs"]),
+                               None if f is None or f["child_tab"] is None else _lib.ptr(f["child_tab"]),
+                               1 if f is None else f["nf"], 0 if f is None else f["kt_real"],
+                               0 if f is None else f["child_side"], 0,
+                               None if f is None or f["child_scale"] is None else _lib.ptr(f["child_scale"]))
         return _lib.PackOp(_lib.ptr(dense), _lib.ptr(self.wp), _lib.ptr(self.g_nc4), _lib.ptr(self.g_woff),
                            _lib.ptr(self.g_choff), _lib.ptr(self.chan_id), _lib.ptr(self.row_id), _lib.ptr(self.g_okoff),
                            _lib.ptr(self.pair_ok), g.n_groups, int(g.g_nc4.max()), g.mt, g.kt, rs, cs, ts, int(block_start),
@@ -205,7 +254,20 @@ class _Side:
         return n
 
     def pack_blocks(self):
+        if self.layout == 4:
+            return self.g.n_groups * self.g.mt * (int(self.g.g_nc4.max()) // 8)
         return self.g.n_groups * (-(-int(self.g.g_nc4.max()) // self.pack_cb()))
+
+    def pack_targets(self):
+        """The sides whose layouts a weight pack must refresh: this one while some batch size runs the v2 / v3 kernels
+        (or nothing is tuned yet), and every v4 companion a tuned batch size launches."""
+        out = []
+        picks = list(self._tuned_v4.values())
+        if not picks or any(p is None for p in picks) or self.layout == 4:
+            out.append(self)
+        for mtw in sorted(set(p[0] for p in picks if p is not None)):
+            out.append(self.v4[mtw])
+        return out
 
     def items_for(self, np_):
         if np_ not in self._items:
@@ -344,6 +406,7 @@ class _Side:
         if hit is not None:
             self._tuned[bp] = tuple(hit)
             self._tuned_v2[bp] = tuple(hit[3:5]) if hit[0] == "v3" else tuple(hit)
+            self._autotune_v4(src, dst, bp, bias, flags, slope)
             return
         scratch = torch.empty_like(dst)
         fl = int(flags) & ~_lib.FLAG_ACCUM
@@ -369,11 +432,112 @@ class _Side:
                 del self._sched[key]            # scratch tiles of the candidates that lost
         self._tuned[bp] = pick
         _tune_cache_put(ck, pick)
+        self._autotune_v4(src, dst, bp, bias, flags, slope)
+
+    # -- fourth generation (bf16 planes) --
+    def v4_splits(self, bp, nc):
+        """K splits of the v4 launch worth timing: enough workgroups to fill the chip, at least two K steps per part."""
+        g = self.g
+        n_units = g.n_groups * self.n_pos * (int(bp) // nc)
+        nks_min = int((g.g_nc4 // 8).min()) * max(1, min(len(l) for l in self.pairs_host))
+        cand = [c for c in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16) if c <= max(1, nks_min // 2) and n_units * c <= 4096]
+        cand = cand or [1]
+        big = [c for c in cand if n_units * c >= 192]
+        return (big[:6] if big else cand[-2:])
+
+    def _v4_buffers(self, bp, nc, split):
+        key = (int(bp), int(nc), int(split))
+        if key not in self._v4_scratch:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.HmvaeError("v4 gather-GEMM: scratch for a new launch shape during a stream capture")
+            g = self.g
+            n_units = g.n_groups * self.n_pos * (int(bp) // nc)
+            self._v4_scratch[key] = (torch.empty(n_units * split * g.mt * 16 * nc, dtype=torch.float32, device=self.device),
+                                     torch.zeros(n_units, dtype=torch.int32, device=self.device))
+        return self._v4_scratch[key]
+
+    def run_v4(self, src, dst, bp, bias, flags, slope, nc, split):
+        assert self.layout == 4
+        g = self.g
+        pb_off, pb_len, items, n_pblk, max_items = self.items_for(1)
+        n_units = g.n_groups * self.n_pos * (int(bp) // nc)
+        scratch = counters = None
+        if split > 1:
+            scratch, counters = self._v4_buffers(bp, nc, split)
+        d = _lib.Gemm4Desc(_lib.ptr(src), _lib.ptr(dst), self.wp.data_ptr(), _lib.ptr(bias), _lib.ptr(self.bias_idx),
+                           _lib.ptr(self.bias_idx2), _lib.ptr(self.g_nc32), _lib.ptr(self.g_woff4), _lib.ptr(self.g_choff),
+                           _lib.ptr(self.g_ntiles), _lib.ptr(self.chan_rows), _lib.ptr(self.dst_rows), _lib.ptr(pb_off),
+                           _lib.ptr(pb_len), _lib.ptr(items), _lib.ptr(scratch), _lib.ptr(counters), g.n_groups, g.mt // 4,
+                           int(nc), g.kt, self.n_pos, int(bp), int(split), n_units, max_items, int(g.g_nc4.max()) // 8,
+                           self.src_ts, self.dst_ts, int(flags), float(slope))
+        _lib.check(_lib.load().hmvae_gather_gemm_v4(C.byref(d), _lib.stream()), "gather_gemm_v4")
+
+    def _run_incumbent(self, src, dst, bp, bias, flags, slope):
+        pick = self._tuned.get(bp)
+        if pick is not None and pick[0] == "v3":
+            return self.run_v3(src, dst, bp, bias, flags, slope, pick[1], pick[2])
+        return self.run_v2(src, dst, bp, bias, flags, slope)
+
+    def _autotune_v4(self, src, dst, bp, bias, flags, slope):
+        """v4 against the v2 / v3 pick of this batch size, on the real operands.  The candidates' layouts are packed here
+        (the step's own pack only refreshes the layouts already chosen)."""
+        if bp in self._tuned_v4 or self.layout == 4:
+            return
+        self._tuned_v4[bp] = None
+        if self._v4_args is None or USE_V4 == "0" or self._last_dense is None or int(bp) % 64:
+            return
+        ck = self.tune_key(bp) + "_v4"
+        hit = _tune_cache_get(ck)
+        if hit is not None and (USE_V4 != "1" or (hit and hit[0])):
+            if hit and hit[0]:
+                sd = self.v4_side(int(hit[0]))
+                if sd is not None:
+                    MultiPack(self.device).run([(sd, self._last_dense)])
+                    if int(hit[2]) > 1:
+                        sd._v4_buffers(bp, int(hit[1]), int(hit[2]))
+                    self._tuned_v4[bp] = (int(hit[0]), int(hit[1]), int(hit[2]))
+                    MultiPack.refresh(self)
+            return
+        scratch = torch.empty_like(dst)
+        fl = int(flags) & ~_lib.FLAG_ACCUM
+        best = (self._time(lambda: self._run_incumbent(src, scratch, bp, bias, fl, slope)) * 0.97, None)
+        if USE_V4 == "1":
+            best = (float("inf"), None)
+        for mtw in (2, 1):
+            sd = self.v4_side(mtw)
+            if sd is None:
+                continue
+            MultiPack(self.device).run([(sd, self._last_dense)])
+            for nc in (128, 64):
+                if int(bp) % nc:
+                    continue
+                for sp in sd.v4_splits(bp, nc):
+                    t = self._time(lambda: sd.run_v4(src, scratch, bp, bias, fl, slope, nc, sp))
+                    if t < best[0]:
+                        best = (t, (mtw, nc, sp))
+        pick = best[1]
+        for mtw in list(self.v4):
+            sd = self.v4[mtw]
+            if sd is None:
+                continue
+            if pick is None or mtw != pick[0]:
+                if not any(p is not None and p[0] == mtw for p in self._tuned_v4.values()):
+                    del self.v4[mtw]                    # layouts and scratch of the shapes that lost
+            else:
+                for key in [k for k in sd._v4_scratch if k[0] == int(bp) and k[1:] != tuple(pick[1:])]:
+                    del sd._v4_scratch[key]
+        self._tuned_v4[bp] = pick
+        _tune_cache_put(ck, list(pick) if pick else [0])
+        if pick is not None:
+            MultiPack.refresh(self)
 
     def run(self, src, dst, bp, bias=None, flags=0, slope=0.2):
         if not USE_V2:
             return self.run_v1(src, dst, bp, bias, flags, slope)
         self.autotune(src, dst, bp, bias, flags, slope)
+        p4 = self._tuned_v4.get(bp)
+        if p4 is not None and self.tune is None:
+            return self.v4[p4[0]].run_v4(src, dst, bp, bias, flags, slope, p4[1], p4[2])
         pick = self._tuned.get(bp)
         if pick is not None and pick[0] == "v3" and self.tune is None:
             return self.run_v3(src, dst, bp, bias, flags, slope, pick[1], pick[2])
@@ -419,7 +583,7 @@ class MaskedGemm:
     """
 
     def __init__(self, device, w_shape, rows_f, chans_f, rows_b, chans_b, pairs_f, pairs_b, x_base, y_base, x_ts, y_ts,
-                 conv_geom=None, bias_rows=None, composite=None):
+                 conv_geom=None, bias_rows=None, composite=None, v4=False):
         n_rows, n_chan, kt = w_shape
         self.w_shape = tuple(int(v) for v in w_shape)
         self.kt = int(kt)
@@ -431,11 +595,19 @@ class MaskedGemm:
         comp = composite
         self.folded = comp is not None
         self.bwd = None
+
+        def g4(rows, chans, k, bits=None):
+            """Deferred row groups of the v4 kernel for one side (planner.make_groups_v4), or None."""
+            if not v4:
+                return None
+            return lambda cap: P.make_groups_v4(rows, chans, k, cap, pair_bits=bits)
         if comp is None:
-            self.fwd = _Side(device, gf, pairs_f, x_base, y_base, bias_rows, x_ts, y_ts, (n_chan * kt, kt, 1))
+            self.fwd = _Side(device, gf, pairs_f, x_base, y_base, bias_rows, x_ts, y_ts, (n_chan * kt, kt, 1),
+                             groups4=g4(rows_f, chans_f, kt))
             if rows_b is not None:
                 # transposed: "rows" are forward channels, "channels" are forward rows
-                self.bwd = _Side(device, gb, pairs_b, y_base, x_base, None, y_ts, x_ts, (kt, n_chan * kt, 1))
+                self.bwd = _Side(device, gb, pairs_b, y_base, x_base, None, y_ts, x_ts, (kt, n_chan * kt, 1),
+                                 groups4=g4(rows_b, chans_b, kt))
         else:
             # Composite relation (planner.compose_conv / merge_channels; hmvae.h, hmvae_pack_op): the gather sides read
             # the SOURCE tensor of the composite (e.g. the coarse tensor in front of Upsample + Unpool) through virtual
@@ -462,11 +634,13 @@ class MaskedGemm:
             if cmap is not None:
                 rf, cf, bits, children = P.merge_channels(rows_f, chans_f, cmap)
                 gfe = P.make_groups(rf, cf, n_vt, pair_bits=bits)
+                gfe4 = g4(rf, cf, n_vt, bits)
                 ctab = child_table(children, len(src_base))
                 ffold = dict(fold, child_tab=ctab, child_side=0)
             elif rmap is not None:
                 rf, cf, bits, children = P.merge_rows(rows_f, chans_f, rmap)
                 gfe = P.make_groups(rf, cf, n_vt, pair_bits=bits)
+                gfe4 = g4(rf, cf, n_vt, bits)
                 ctab = child_table(children, len(dst_base))
                 if max(len(v) for v in children.values()) > 2:
                     raise NotImplementedError("pooled rows with more than two children")
@@ -481,23 +655,28 @@ class MaskedGemm:
                 ffold = dict(fold, child_tab=ctab, child_side=1, child_scale=scale)
             else:
                 gfe = P.make_groups(rows_f, chans_f, n_vt)
+                gfe4 = g4(rows_f, chans_f, n_vt)
                 ffold = dict(fold)
             self.fwd = _Side(device, gfe, pe, src_base, dst_base, b1, src_ts, y_ts, (n_chan * kt, kt, 1), fold=ffold,
-                             bias_rows2=b2)
+                             bias_rows2=b2, groups4=gfe4)
             if rows_b is not None:
                 pb = P.transpose_pairs(pe, int(comp["n_src_pos"]))
                 if cmap is not None:
                     rb, cb_, bits_b, _ = P.merge_channels_transposed(rows_b, chans_b, cmap, len(src_base))
                     gbe = P.make_groups(rb, cb_, n_vt, pair_bits=bits_b)
+                    gbe4 = g4(rb, cb_, n_vt, bits_b)
                     bfold = dict(fold, child_tab=ctab, child_side=1)
                 elif rmap is not None:
                     rb, cb_, bits_b, _ = P.merge_rows_transposed(rows_b, chans_b, rmap)
                     gbe = P.make_groups(rb, cb_, n_vt, pair_bits=bits_b)
+                    gbe4 = g4(rb, cb_, n_vt, bits_b)
                     bfold = dict(fold, child_tab=ctab, child_side=0, child_scale=scale)
                 else:
                     gbe = P.make_groups(rows_b, chans_b, n_vt)
+                    gbe4 = g4(rows_b, chans_b, n_vt)
                     bfold = dict(fold)
-                self.bwd = _Side(device, gbe, pb, dst_base, src_base, None, y_ts, src_ts, (kt, n_chan * kt, 1), fold=bfold)
+                self.bwd = _Side(device, gbe, pb, dst_base, src_base, None, y_ts, src_ts, (kt, n_chan * kt, 1), fold=bfold,
+                                 groups4=gbe4)
         # weight gradient tiles: forward grouping, or (masked convs) a grouping keyed by input block whose tiles have
         # several 16-row pieces per activation load and no union waste
         gw = gf
@@ -972,7 +1151,7 @@ def conv_gemm(device, neigh, cin, cout, kt, stride, pad, pad_mode, t_in, need_dx
     if composite is None and (upsample or unpool_src is not None or pool_groups is not None):
         raise _lib.HmvaeError("the layers around this convolution cannot be folded into it (HMVAE_FOLD=0 or limits)")
     op = MaskedGemm(device, (cout, cin, kt), rows_f, chans_f, rows_b, chans_b, pairs_f, pairs_b, x_base, y_base, 1, 1,
-                    conv_geom=geom, composite=composite)
+                    conv_geom=geom, composite=composite, v4=True)
     op.t_in, op.t_out = t_in, t_out
     op.fused_front = bool(upsample or unpool_src is not None)
     op.fused_pool = pool_groups is not None
@@ -1192,27 +1371,73 @@ def vae_loss_finalize(mse_partial, kl0_partial, kld_partial, inv_n6, inv_nR, inv
 
 
 class MultiPack:
-    """All weight packs of a model as one launch; the descriptor table is rebuilt only if a tensor moved."""
+    """All weight packs of a model as one launch per layout; the descriptor tables are rebuilt only if a tensor moved or a
+    side's tuned launches changed the layouts it needs (never inside a stream capture: a side that settles on the v4
+    kernel during a warm-up step refreshes every live MultiPack that holds it right away, MultiPack.refresh)."""
+    _live = None
 
     def __init__(self, device):
+        import weakref
         self.device = device
         self.key = None
-        self.table = None
+        self.tables = []
+        self._last = None
+        if MultiPack._live is None:
+            MultiPack._live = weakref.WeakSet()
+        MultiPack._live.add(self)
 
-    def run(self, sides_and_weights):
-        key = tuple((id(s), w.data_ptr()) for s, w in sides_and_weights)
-        if key != self.key:
-            arr = (_lib.PackOp * len(sides_and_weights))()
+    @staticmethod
+    def _targets(sides_and_weights):
+        targets = []
+        for s, w in sides_and_weights:
+            s._last_dense = w
+            for t in (s.pack_targets() if s.layout == 2 else [s]):
+                targets.append((t, w))
+        return targets
+
+    def _build(self, targets, key):
+        self.tables = []
+        for layout in (2, 4):
+            lst = [(s, w) for s, w in targets if s.layout == layout]
+            if not lst:
+                continue
+            arr = (_lib.PackOp * len(lst))()
             start = 0
             kmax = 1
-            for i, (s, w) in enumerate(sides_and_weights):
+            for i, (s, w) in enumerate(lst):
                 arr[i] = s.pack_op(w, start)
                 start += s.pack_blocks()
-                kmax = max(kmax, s.pack_lds_floats())
-            self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-            self.n_ops, self.total, self.kmax, self.key = len(sides_and_weights), start, kmax, key
-        _lib.check(_lib.load().hmvae_pack_weights_multi(self.table.data_ptr(), self.n_ops, self.total, self.kmax,
-                                                        _lib.stream()), "pack_weights_multi")
+                kmax = max(kmax, s.g.kt if layout == 4 else s.pack_lds_floats())
+            table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            self.tables.append((layout, table, len(lst), start, kmax))
+        self.key = key
+
+    @classmethod
+    def refresh(cls, side):
+        """`side` changed the layouts it needs: rebuild the tables of every MultiPack whose last list holds it."""
+        for mp in list(cls._live or ()):
+            if mp._last is not None and any(s is side for s, _ in mp._last):
+                targets = cls._targets(mp._last)
+                mp._build(targets, tuple((id(s), w.data_ptr()) for s, w in targets))
+
+    def run(self, sides_and_weights):
+        """sides_and_weights: [(side, dense weight)].  A side stands for the layouts its tuned launches read
+        (_Side.pack_targets): the fp32 fragments of the v2 / v3 kernels and / or bf16-plane companions of the v4 kernel,
+        which have their own pack kernel (a second launch when any is present)."""
+        targets = self._targets(sides_and_weights)
+        self._last = list(sides_and_weights)
+        key = tuple((id(s), w.data_ptr()) for s, w in targets)
+        if key != self.key:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.HmvaeError("weight pack: new descriptor table during a stream capture")
+            self._build(targets, key)
+        lib = _lib.load()
+        for layout, table, n_ops, total, kmax in self.tables:
+            if layout == 4:
+                _lib.check(lib.hmvae_pack_weights_v4(table.data_ptr(), n_ops, total, kmax, _lib.stream()), "pack_weights_v4")
+            else:
+                _lib.check(lib.hmvae_pack_weights_multi(table.data_ptr(), n_ops, total, kmax, _lib.stream()),
+                           "pack_weights_multi")
 
 
 class MultiReduce:

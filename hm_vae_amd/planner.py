@@ -14,7 +14,7 @@ import numpy as np
 class GroupSet:
     """Row groups + channel lists for one masked dense matrix W[row, chan, tap]."""
 
-    def __init__(self, mt, groups, kt, row_chans=None, pair_bits=None):
+    def __init__(self, mt, groups, kt, row_chans=None, pair_bits=None, chan_pad=4):
         """groups: [(rows, chans)]; row_chans: dense row id -> set of channels that row may read (its mask).
         When rows of several blocks share a group, the union list holds channels that are masked out for some
         rows: pair_ok marks the (row, channel) pairs that are really in the mask.  pair_bits(row, chan) -> uint8
@@ -33,7 +33,7 @@ class GroupSet:
             assert 0 < len(rows) <= rows_per, (len(rows), rows_per)
             row_id[gi, :len(rows)] = rows
             nch = len(chans)
-            pad = (-nch) % 4
+            pad = (-nch) % int(chan_pad)
             g_choff.append(len(chan_id))
             chan_id.extend(list(chans) + [-1] * pad)
             nc4 = (nch + pad) // 4
@@ -84,8 +84,8 @@ class GroupSet:
                 (self.g_nch * self.kt).astype(np.int32))
 
 
-def _merge_units(units, cap):
-    """Greedy agglomeration: merge two units when rows fit and the summed channel lists shrink."""
+def _merge_units(units, cap, chan_pad=4):
+    """Greedy agglomeration: merge two units when rows fit and the summed (padded) channel lists shrink."""
     units = [(list(r), set(c)) for r, c in units]
     while True:
         best = None
@@ -94,7 +94,7 @@ def _merge_units(units, cap):
                 if len(units[i][0]) + len(units[j][0]) > cap:
                     continue
                 u = units[i][1] | units[j][1]
-                pad4 = lambda n: (n + 3) // 4 * 4
+                pad4 = lambda n: -(-n // chan_pad) * chan_pad
                 gain = pad4(len(units[i][1])) + pad4(len(units[j][1])) - pad4(len(u))
                 if gain > 0 and (best is None or gain > best[0]):
                     best = (gain, i, j)
@@ -134,11 +134,44 @@ def make_groups(joint_rows, joint_chans, kt, mt_choices=(1,), pair_bits=None):
         units = _merge_units(units, cap)
         groups = [(r, sorted(c)) for r, c in units]
         groups.sort(key=lambda g: min(g[0]))
+        if os.environ.get("HMVAE_GROUP_ORDER", "rows") == "len":
+            # longest reduction first: the dispatcher hands out workgroups in index order, so the long groups of a layer
+            # (K lengths differ up to 4x) start early and the short ones fill the tail
+            groups.sort(key=lambda g: -len(g[1]))
         gs = GroupSet(mt, groups, kt, row_chans, pair_bits)
         score = gs.mfma_cost() * eff[mt]
         if best is None or score < best[0]:
             best = (score, gs)
     return best[1]
+
+
+def make_groups_v4(joint_rows, joint_chans, kt, cap, pair_bits=None):
+    """Row groups of the bf16-plane gather-GEMM (hmvae_gather_gemm_v4): up to `cap` rows (64 or 128 = four waves x one or
+    two 16-row tiles) sharing one channel list padded to 32.  A workgroup spends mtw x (32-channel steps) matrix time on a
+    group however many of its tiles are live, so rows with IDENTICAL channel lists are pooled across blocks before they are
+    cut (a dense layer becomes ceil(rows / cap) full groups), and groups are merged while the padded lists shrink."""
+    pools, order = {}, []
+    row_chans = {}
+    for rows, chans in zip(joint_rows, joint_chans):
+        fs = frozenset(chans)
+        if fs not in pools:
+            pools[fs] = []
+            order.append(fs)
+        pools[fs].extend(rows)
+        for r in rows:
+            row_chans[r] = fs
+    units = []
+    for fs in order:
+        rows = pools[fs]
+        n_chunks = -(-len(rows) // cap)
+        per = -(-len(rows) // n_chunks)
+        per = -(-per // 16) * 16                      # whole tiles, evenly filled groups
+        for k in range(0, len(rows), per):
+            units.append((rows[k:k + per], list(fs)))
+    units = _merge_units(units, cap, chan_pad=32)
+    groups = [(r, sorted(c)) for r, c in units]
+    groups.sort(key=lambda g: min(g[0]))
+    return GroupSet(cap // 16, groups, kt, row_chans, pair_bits, chan_pad=32)
 
 
 # ---------------------------------------------------------------------------------------------

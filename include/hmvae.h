@@ -152,6 +152,55 @@ typedef struct {
 int hmvae_gather_gemm_v3(const hmvae_conv3_desc* desc, hmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fourth-generation gather-GEMM: the same contract as hmvae_gather_gemm_v2 (SkeletonConv forward /
+ * backward-data, skeleton.py:95-105, with everything folded into its weights), computed on the bf16
+ * matrix pipe with fp32-grade results.  Every fp32 operand is the exact sum of three bf16 planes
+ * (round to nearest at each level); of the nine cross products the six of weight >= 2^-16 carry
+ * everything above 2^-24 of a product and run as v_mfma_f32_16x16x32_bf16 with fp32 accumulation --
+ * 96 issue cycles where v_mfma_f32_16x16x4_f32 needs 256 for the same K.
+ *   weights     : split ONCE per step by hmvae_pack_weights_v4 into MFMA A-operand order
+ *                 wp4[group][c32 < nc32][tap < kt][tile < mtg][plane < 3][lane (m, kk)][8 bf16],
+ *                 channel of (lane, j) = c32*32 + kk*8 + j of the group's list (lists are padded to 32);
+ *   activations : stay fp32 in HBM ([rows][bp]); a workgroup (4 waves) stages the 32 rows of a K step
+ *                 (32 channels of one source position) for its 64 / 128 batch columns into LDS as three
+ *                 row-major bf16 planes (one split per element per workgroup) and every wave takes
+ *                 its B operands from them with the transposing read ds_read_b64_tr_b16.
+ * A UNIT is (group, output position, block of nc = 64|128 columns); wave w of the workgroup owns row
+ * tiles w*mtw .. w*mtw + mtw - 1 of the group (mtg = 4*mtw tiles of 16 rows per group).  The K steps
+ * (c32, item) of a unit are cut into n_split equal parts, one workgroup each; for n_split > 1 the raw
+ * tiles go to scratch[unit][part] and the LAST workgroup of a unit to finish (counters[unit], an
+ * agent-scope atomic after a release fence) sums the parts in part order and runs the epilogue --
+ * deterministic, no second launch, nobody waits.  counters must be zero before the first launch and
+ * are left zero by every launch.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* src;
+    float* dst;
+    const uint16_t* wp4;     /* packed bf16 planes (hmvae_pack_weights_v4) */
+    const float* bias;
+    const int32_t* bias_idx; /* [n_groups*mtg*16], as v2 */
+    const int32_t* bias_idx2;/* NULL or as v2 */
+    const int32_t* g_nc32;   /* [n_groups] 32-channel steps of the group */
+    const int32_t* g_woff4;  /* [n_groups] offset of the group's weights in 1 KB fragments */
+    const int32_t* g_choff;  /* [n_groups] offset of the group's channel list in chan_rows */
+    const int32_t* g_ntiles; /* [n_groups] row tiles that hold at least one valid row */
+    const int32_t* chan_rows;/* src row base per listed channel (dummy entries: a valid row, weight 0) */
+    const int32_t* dst_rows; /* [n_groups*mtg*16] dst row base or -1 */
+    const int32_t* pb_off;   /* [n_pos] first item of the output position */
+    const int32_t* pb_len;   /* [n_pos] */
+    const int32_t* items;    /* pairs of int32: source position q, (virtual) tap */
+    float* scratch;          /* [n_units][n_split][mtg*16][nc] (n_split > 1) */
+    int32_t* counters;       /* [n_units] (n_split > 1) */
+    int32_t n_groups, mtw, nc, kt, n_pos, bp;
+    int32_t n_split, n_units;            /* n_units = n_groups * n_pos * (bp / nc) */
+    int32_t max_items, max_nc32;         /* largest pb_len (<= 256) / g_nc32 (<= 32) */
+    int32_t src_ts, dst_ts, flags;
+    float slope;
+} hmvae_gemm4_desc;
+
+int hmvae_gather_gemm_v4(const hmvae_gemm4_desc* desc, hmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Weight-gradient GEMM (autograd of skeleton.py:95-105 / nn.Linear w.r.t. weight), split over the
  * (position, batch) reduction into `n_split` slabs, then a deterministic reduce into the dense grad.
  * slab[s][tile][mt*16][64] = sum_{t,b in split s} dz[dz_rows[g,r] + t*dz_ts][b] *
@@ -298,6 +347,13 @@ typedef struct {
  * kt*16 for a composite op (fold_kt <= 16, 16-row groups) */
 int hmvae_pack_weights_multi(const hmvae_pack_op* ops_dev, int32_t n_ops, int32_t total_blocks, int32_t max_lds_floats,
                              hmvae_stream_t stream);
+
+/* Weight packs for hmvae_gather_gemm_v4: the effective matrix of a hmvae_pack_op -- mask, virtual taps, merged
+ * rows / channels: same tables, lists padded to 32 channels, g_nc4 = 8 * nc32 -- split into three bf16 planes in the
+ * layout above.  One workgroup per (group, row tile, 32 channels); op i owns the blocks block_start .. block_start +
+ * n_groups * mt * max_nc4 / 8 (mt = tiles per group, g_woff in 1 KB fragments, packed = the uint16 buffer). */
+int hmvae_pack_weights_v4(const hmvae_pack_op* ops_dev, int32_t n_ops, int32_t total_blocks, int32_t max_kt,
+                          hmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Element-wise / reduction kernels on SoA activations

@@ -68,6 +68,40 @@ def _level_neigh(level):
     return topology.find_neighbor(edges, 2)
 
 
+def v4_variants(side, bp):
+    """(companion side, columns per unit, K split) of every launch shape of the bf16-plane gather-GEMM (gemm_v4.hip) the
+    problem supports: 64- and 128-row groups, 64 / 128 columns, unsplit and split three ways (last-arriver reduction)."""
+    out = []
+    for mtw in (1, 2):
+        sd = side.v4_side(mtw)
+        if sd is None:
+            continue
+        for nc in (64, 128):
+            if bp % nc == 0:
+                out.extend((sd, nc, sp) for sp in (1, 3))
+    return out
+
+
+def check_v4(side, dense, src, bp, bias, flags, ref, read_back, what):
+    """Every v4 launch shape of `side` against the oracle's result `ref` (1e-4), plus the accumulate flag once."""
+    from hm_vae_amd import ops, _lib
+    var = v4_variants(side, bp)
+    assert var, what
+    packed = set()
+    for sd, nc, sp in var:
+        if id(sd) not in packed:
+            ops.MultiPack(src.device).run([(sd, dense)])
+            packed.add(id(sd))
+        out = torch.full((read_back[0], bp), float("nan"), device=src.device)
+        sd.run_v4(src, out, bp, bias, flags, 0.2, nc, sp)
+        assert rel_err(read_back[1](out), ref) < TOL, (what, sd.g.mt, nc, sp)
+        if sp == 3 and not (flags & _lib.FLAG_LEAKY):
+            sd.run_v4(src, out, bp, bias, flags | _lib.FLAG_ACCUM, 0.2, nc, sp)
+            assert rel_err(read_back[1](out), 2 * ref) < TOL, (what, "accumulate", sd.g.mt, nc, sp)
+            sd.run_v4(src, out, bp, bias, flags, 0.2, nc, sp)               # counters were left at zero: a third launch agrees
+            assert rel_err(read_back[1](out), ref) < TOL, (what, "relaunch", sd.g.mt, nc, sp)
+
+
 CONV_CASES = [
     dict(level=0, cin=144, cout=288, K=15, s=2, T=64, B=5, mode="reflect", leaky=False),      # enc0 of len64
     dict(level=3, cin=336, cout=672, K=15, s=2, T=8, B=70, mode="reflect", leaky=False),       # enc3, pad ~ T
@@ -156,6 +190,13 @@ def test_skeleton_conv_fwd_bwd(dev, case):
     op.backward_data(gys, dxs, bp, accumulate=True)
     assert rel_err(bct_from_soa(dxs, B, cin, T).numpy(), 2 * x.grad.numpy()) < TOL
 
+    # the bf16-plane kernel (v4) in every launch shape, forward and backward-data, against the same reference
+    lk = _lib.FLAG_LEAKY if case["leaky"] else 0
+    check_v4(op.fwd, wd_poison, xs, bp, b.detach().to(dev), lk, y.detach().numpy(),
+             (cout * T_out, lambda o: bct_from_soa(o, B, cout, T_out).numpy()), "fwd")
+    check_v4(op.bwd, wd_poison, gys, bp, None, 0, x.grad.numpy(),
+             (cin * T, lambda o: bct_from_soa(o, B, cin, T).numpy()), "bwd")
+
     # the window kernel (v3) in every workgroup shape, forward and backward-data, against the same reference
     n_v3 = 0
     for chunk, ts in ((8, 1), (4, 2), (2, 4), (1, 8)):
@@ -226,6 +267,11 @@ def test_conv_behind_upsample_unpool(dev, level, ch, co, Tc, B):
     dxs = torch.full((n_c * ch * Tc, bp), float("nan"), device=dev)
     op.backward_data(gys, dxs, bp)
     assert rel_err(bct_from_soa(dxs, B, n_c * ch, Tc).numpy(), xc.grad.numpy()) < TOL
+    wpo = wd + (1 - mask.to(dev)) * 3.0
+    check_v4(op.fwd, wpo, xs, bp, b.detach().to(dev), _lib.FLAG_LEAKY, y.detach().numpy(),
+             (cout * T, lambda o: bct_from_soa(o, B, cout, T).numpy()), "fwd (upsample + unpool folded)")
+    check_v4(op.bwd, wpo, gys, bp, None, 0, xc.grad.numpy(),
+             (n_c * ch * Tc, lambda o: bct_from_soa(o, B, n_c * ch, Tc).numpy()), "bwd (upsample + unpool folded)")
     us, _ = soa_from_bct(U.detach(), dev)
     dw = torch.zeros(cout, cin, K, device=dev)
     slab = torch.empty(op.slab_floats(bp), device=dev)
@@ -278,6 +324,11 @@ def test_conv_followed_by_pool(dev, level, ci, co, T, B):
     dxs = torch.full((cin * T, bp), float("nan"), device=dev)
     op.backward_data(dps, dxs, bp)
     assert rel_err(bct_from_soa(dxs, B, cin, T).numpy(), x.grad.numpy()) < TOL
+    wpo = wd + (1 - mask.to(dev)) * 3.0
+    check_v4(op.fwd, wpo, xs, bp, b.detach().to(dev), _lib.FLAG_LEAKY, a.detach().numpy(),
+             (n_p * co * T_out, lambda o: bct_from_soa(o, B, n_p * co, T_out).numpy()), "fwd (pool folded)")
+    check_v4(op.bwd, wpo, dps, bp, None, 0, x.grad.numpy(),
+             (cin * T, lambda o: bct_from_soa(o, B, cin, T).numpy()), "bwd (pool folded)")
     dw = torch.zeros(cout, cin, K, device=dev)
     slab = torch.empty(op.slab_floats(bp), device=dev)
     op.backward_weight(dps, xs, dw, bp, slab)
