@@ -23,6 +23,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2516.6    # same guide: bf16 MFMA = 16x the fp32 rate (~2.5 PFLOP/s dense)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.3 TB/s achievable with a float4 copy)
 
 
@@ -94,9 +95,11 @@ class KernelTimer:
             a[1] += fl
             a[2] += 1
             a[3] += issued
-            k = per_kernel.setdefault(cname, [0.0, 0])
+            k = per_kernel.setdefault(cname, [0.0, 0, 0.0, 0.0])
             k[0] += ms
             k[1] += 1
+            k[2] += fl
+            k[3] += issued
         self.per_kernel = per_kernel
         return agg
 
@@ -107,20 +110,31 @@ def instrument_gemms(engine, timer, bp):
     from hm_vae_amd import _lib
     restore = []
     all_ops = engine.enc_conv + engine.dec_conv + engine.enc_lin + list(engine.dec_lin.values())
-    fam = "gather_gemm (gather_gemm2_kernel | conv_window_kernel)"
+    fam = "gather_gemm (gather_gemm4_kernel | gather_gemm2_kernel | conv_window_kernel)"
+
+    def issued_per_col(side, bp_):
+        """Flops per batch column the matrix pipe executes for this side's tuned launch: fp32 MFMAs of the v2 / v3 kernels
+        (2 per multiply-add), or the SIX bf16 MFMAs per 16x16x32 block of the v4 kernel (the three-plane cross terms)."""
+        n_items = sum(len(l) for l in side.pairs_host)
+        p4 = side._tuned_v4.get(bp_)
+        if p4 is None:
+            return 2.0 * side.g.mfma_cost() * n_items
+        sd = side.v4[p4[0]]
+        nt = sd.g_ntiles.cpu().numpy()
+        tiles = ((nt + p4[0] - 1) // p4[0]) * p4[0]          # a wave with one live tile multiplies all mtw of its tiles
+        return 6.0 * 2.0 * 16.0 * float((tiles * (sd.g.g_nc4 // 8) * 32).sum()) * n_items
     for op in all_ops:
         useful_f = 2.0 * op.useful_macs_per_col          # algorithmic: the masked convolution's own multiply-adds
         for side in (op.fwd, op.bwd):
             if side is None:
                 continue
-            issued = 2.0 * side.g.mfma_cost() * sum(len(l) for l in side.pairs_host)   # what the MFMAs execute
-            restore.append((side, "run", timer.wrap_op(side, "run", fam, lambda *a, _f=useful_f, _i=issued, **k:
-                                                       (_f * a[2], _i * a[2]) if len(a) > 2 else (0.0, 0.0))))
+            restore.append((side, "run", timer.wrap_op(side, "run", fam, lambda *a, _f=useful_f, _s=side, **k:
+                                                       (_f * a[2], issued_per_col(_s, a[2]) * a[2]) if len(a) > 2 else (0.0, 0.0))))
         restore.append((op, "backward_weight", timer.wrap_op(op, "backward_weight",
                                                              "wgrad (wgrad_bf3_kernel | wgrad_lds_kernel | wgrad_kernel | wreduce_kernel)",
                                                              lambda *a, _f=useful_f, **k: _f * a[3])))
     lib = _lib.load()
-    for cname in ("hmvae_gather_gemm_v2", "hmvae_gather_gemm_v3", "hmvae_wgrad_gemm", "hmvae_wgrad_reduce"):
+    for cname in ("hmvae_gather_gemm_v2", "hmvae_gather_gemm_v3", "hmvae_gather_gemm_v4", "hmvae_wgrad_gemm", "hmvae_wgrad_reduce"):
         restore.append((lib, cname, timer.wrap_c(lib, cname)))
     return restore
 
@@ -478,23 +492,38 @@ def main():
         label, (ms, fl, cnt, issued) = fam
         tfl = fl / (ms * 1e-3) / 1e12
         traffic, tsrc = load_traffic(label, B, args.phase)
+        # fp32 and bf16 issued flops do not add up to one rate: with both gather kernels in the step the family-level
+        # issued rate is left out and per_entry_point carries one per pipe
+        mixed = "hmvae_gather_gemm_v4" in timer.per_kernel and "hmvae_gather_gemm_v2" in timer.per_kernel
         out["roofline"] = {"kernel": label, "bound": "mfma", "achieved": tfl, "peak": PEAK_F32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": tfl / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                            "traffic_unit": "HBM-side bytes per launch (PMC)", "traffic_source": tsrc,
                            "launches_per_step": cnt // n_inst, "avg_launch_us": ms / cnt * 1e3,
                            "timing": "HIP events on the launch stream around each C-ABI launch call of the family, %d extra "
                                      "eager one-stream steps of the same workload" % n_inst,
-                           "per_entry_point": {k: {"ms_per_step": v[0] / n_inst, "launches_per_step": v[1] // n_inst}
+                           "per_entry_point": {k: dict({"ms_per_step": v[0] / n_inst, "launches_per_step": v[1] // n_inst,
+                                                        "algorithmic_TFLOP/s": v[2] / (v[0] * 1e-3) / 1e12},
+                                                       **({"issued_bf16_TFLOP/s": v[3] / (v[0] * 1e-3) / 1e12,
+                                                           "issued_frac_of_bf16_peak": v[3] / (v[0] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
+                                                          if k == "hmvae_gather_gemm_v4" else
+                                                          {"issued_fp32_TFLOP/s": v[3] / (v[0] * 1e-3) / 1e12,
+                                                           "issued_frac_of_fp32_peak": v[3] / (v[0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+                                                          if k.startswith("hmvae_gather") else {}))
                                                for k, v in timer.per_kernel.items()},
                            "flops_per_step_effective": fl / n_inst,
                            "flops_per_step_issued": issued / n_inst,
-                           "issued_TFLOP/s": issued / (ms * 1e-3) / 1e12,
-                           "note": "achieved = algorithmic flops of the masked convolutions / kernel time; the MFMAs "
-                                   "issue fewer flops than that where taps are folded (enc3, dec0) and more where 16-row "
-                                   "tiles are padded: issued_TFLOP/s is what the matrix pipe executes",
+                           "issued_TFLOP/s": None if mixed else issued / (ms * 1e-3) / 1e12,
+                           "note": "achieved = algorithmic (fp32, mask-effective) flops of the convolutions / kernel time, "
+                                   "priced against the fp32 MFMA peak the reference's arithmetic would need.  The family mixes "
+                                   "two pipes: hmvae_gather_gemm_v2 issues fp32 MFMAs (fewer flops than algorithmic where "
+                                   "taps are folded, more where 16-row tiles are padded), hmvae_gather_gemm_v4 issues six "
+                                   "bf16 MFMAs per fp32-equivalent block (three exact bf16 planes per operand); "
+                                   "per_entry_point prices each against its own pipe's dense peak (the family-level issued rate "
+                                   "is null while both run: the two kinds of flops do not add)",
                            "all_kernels": {k: {"ms_per_step": v[0] / n_inst, "TFLOP/s": v[1] / (v[0] * 1e-3) / 1e12,
                                                "frac": v[1] / (v[0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                               "issued_TFLOP/s": v[3] / (v[0] * 1e-3) / 1e12,
+                                               "issued_TFLOP/s": (None if (mixed and k.startswith("gather")) else
+                                                                  v[3] / (v[0] * 1e-3) / 1e12),
                                                "launches_per_step": v[2] // n_inst}
                                            for k, v in agg.items()}}
         conv_flops_step = 3.0 * eng.flops_per_seq * B

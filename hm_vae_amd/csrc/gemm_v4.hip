@@ -34,6 +34,19 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef HMVAE_STAMP
+#define STAMP4(i)                                                                                  \
+    do {                                                                                           \
+        if (d.debug && threadIdx.x == 0) {                                                         \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            d.debug[(size_t)blockIdx.x * 8 + (i)] = t_;                                            \
+        }                                                                                          \
+    } while (0)
+#else
+#define STAMP4(i)
+#endif
+
 namespace {
 
 constexpr int V4_MAX_ITEMS = 256;
@@ -89,6 +102,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
     const int pb = r0 % d.n_pos;
     const int g = r0 / d.n_pos;
 
+    STAMP4(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();                                             // tables visible
+    STAMP4(1);
 
     // Iterator over K steps (c32, item), item fastest; clamped at the part's last step (the over-fetch is never used).
     // Operands run D K steps ahead of the MFMAs in a ring of R = D + 1 statically named register sets (the trip body is
@@ -206,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
 #pragma unroll
         for (int u = 0; u < D; ++u) fetch(rb[u], ra[u], M);
         const int trips = n / R;
+        STAMP4(2);
         for (int t = 0; t < trips; ++t) {
 #pragma unroll
             for (int u = 0; u < R; ++u) {
@@ -235,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
     }
 
     // ---- epilogue ----
+    STAMP4(3);
     const int n_ = (int)li, rq = (int)kk;
     auto finish = [&](f32x4 s, int row_in_group, int colbase) {     // bias / activation / accumulate / 16-byte store
         const int drow = d.dst_rows[g * RP + row_in_group];
@@ -276,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
             const int row = idx / CQ, c4 = idx - row * CQ;
             finish(*(const f32x4*)(tile + row * NC + c4 * 4), row, c4 * 4);
         }
+        STAMP4(6);
         return;
     }
     // Split K, hand-off between workgroups inside the launch (the per-XCD L2s are not coherent with each other and a CU's
@@ -292,8 +310,10 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    STAMP4(4);
     if (tid == 0) *lds_flag = __hip_atomic_fetch_add(d.counters + unit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    STAMP4(5);
     if (*lds_flag != S - 1) return;
     for (int idx = tid; idx < live_rows * CQ; idx += 256) {
         const int row = idx / CQ, c4 = idx - row * CQ;
@@ -304,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
         finish(s, row, c4 * 4);
     }
     if (tid == 0) __hip_atomic_store(d.counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left as found
+    STAMP4(6);
 }
 
 // ---- weight pack: effective matrix -> three bf16 planes in A-operand order ----

@@ -469,7 +469,7 @@ class _Side:
                            _lib.ptr(self.g_ntiles), _lib.ptr(self.chan_rows), _lib.ptr(self.dst_rows), _lib.ptr(pb_off),
                            _lib.ptr(pb_len), _lib.ptr(items), _lib.ptr(scratch), _lib.ptr(counters), g.n_groups, g.mt // 4,
                            int(nc), g.kt, self.n_pos, int(bp), int(split), n_units, max_items, int(g.g_nc4.max()) // 8,
-                           self.src_ts, self.dst_ts, int(flags), float(slope))
+                           self.src_ts, self.dst_ts, int(flags), float(slope), _lib.ptr(DEBUG_BUF))
         _lib.check(_lib.load().hmvae_gather_gemm_v4(C.byref(d), _lib.stream()), "gather_gemm_v4")
 
     def _run_incumbent(self, src, dst, bp, bias, flags, slope):

@@ -196,6 +196,7 @@ typedef struct {
     int32_t max_items, max_nc32;         /* largest pb_len (<= 256) / g_nc32 (<= 32) */
     int32_t src_ts, dst_ts, flags;
     float slope;
+    uint64_t* debug;         /* NULL in production; a diagnostic build (-DHMVAE_STAMP) writes 8 s_memtime stamps per workgroup */
 } hmvae_gemm4_desc;
 
 int hmvae_gather_gemm_v4(const hmvae_gemm4_desc* desc, hmvae_stream_t stream);
