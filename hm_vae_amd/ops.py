@@ -49,6 +49,7 @@ WGRAD_LDS = _os.environ.get("HMVAE_WGRAD_LDS", "auto")
 # significant cross terms run on the bf16 matrix pipe (csrc/wgrad_bf3.hip): fp32-grade sums at 3/8 of the fp32 MFMA issue
 # cycles.  A candidate of the autotuner unless HMVAE_WGRAD_BF3=0; HMVAE_WGRAD_LDS=2 forces it wherever it applies.
 WGRAD_BF3 = _os.environ.get("HMVAE_WGRAD_BF3", "1") != "0"
+KEEP_IO = False          # set by tools/tune_in_situ.py: sides remember their last operands
 GATHER_WPOS = _os.environ.get("HMVAE_GATHER_WPOS", "1") != "0"       # let the autotuner time the position-per-wave launch shape
 # the mode-2 GEMM writes the dense gradient from its own epilogue where the reduction is not split (no slab, no reduce launch)
 FUSE_WREDUCE = _os.environ.get("HMVAE_FUSE_WREDUCE", "1") != "0"
@@ -534,6 +535,8 @@ class _Side:
     def run(self, src, dst, bp, bias=None, flags=0, slope=0.2):
         if not USE_V2:
             return self.run_v1(src, dst, bp, bias, flags, slope)
+        if KEEP_IO and not torch.cuda.is_current_stream_capturing():
+            self._last_io = (src, dst, torch.empty_like(dst))      # tools/tune_in_situ.py times candidates on these
         self.autotune(src, dst, bp, bias, flags, slope)
         p4 = self._tuned_v4.get(bp)
         if p4 is not None and self.tune is None:

@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--passes", type=int, default=2)
     ap.add_argument("--seq-len", type=int, default=0, help="override train_seq_len (trajectory model: config 5 quotes 64)")
     ap.add_argument("--fast", action="store_true", help="weight-gradient splits 1, 2, 3, 4, 6, 8 only")
+    ap.add_argument("--no-v4", action="store_true", help="leave the v4 (bf16-plane) gather choices as the autotuner made them")
+    ap.add_argument("--only", default="", help="comma list of knob kinds to walk: g, g4, w (default: all)")
     ap.add_argument("--out", default=os.path.join(ROOT, "hm_vae_amd", "assets", "tune_mi355x.json"))
     a = ap.parse_args()
     import bench
@@ -44,6 +46,7 @@ def main():
     from hm_vae_amd.utils_common import get_config
     from hm_vae_amd.graph_step import GraphedStep, retire
     dev = torch.device("cuda:0")
+    ops.KEEP_IO = True
     cfg = get_config(a.config)
     if a.seq_len:
         cfg["train_seq_len"] = a.seq_len
@@ -88,6 +91,8 @@ def main():
         for sd in (op.fwd, op.bwd):
             if sd is not None and bp in sd._tuned:
                 knobs.append(("g", sd))
+                if sd._v4_args is not None and ops.USE_V4 != "0" and not a.no_v4:
+                    knobs.append(("g4", sd))
         if bp in op._split_tuned:
             knobs.append(("w", op))
     base = min(measure(), measure())
@@ -96,9 +101,48 @@ def main():
     for ps in range(a.passes):
         improved = False
         for kind, obj in knobs:
+            if a.only and kind not in a.only.split(","):
+                continue
             base = measure()                 # the incumbent, re-timed: clocks drift over a run of several minutes
             noise = 0.002 * base
-            if kind == "g":
+            if kind == "g4":
+                # the bf16-plane kernel's launch shape (rows per group, columns per unit, K split) or None = the v2 / v3
+                # pick: every shape is timed alone first (cheap), the three best and "off" are tried in the step
+                cur = obj._tuned_v4.get(bp)
+                src_dst = getattr(obj, "_last_io", None)
+                cands = []
+                for mtw in (1, 2):
+                    sd4 = obj.v4_side(mtw)
+                    if sd4 is None:
+                        continue
+                    for nc in (128, 64):
+                        if bp % nc:
+                            continue
+                        for sp in sd4.v4_splits(bp, nc):
+                            cands.append((mtw, nc, sp))
+                if src_dst is not None and len(cands) > 3:
+                    timed = []
+                    for c in cands:
+                        sd4 = obj.v4_side(c[0])
+                        ops.MultiPack(dev).run([(sd4, obj._last_dense)])
+                        timed.append((obj._time(lambda: sd4.run_v4(src_dst[0], src_dst[2], bp, None, 0, 0.2, c[1], c[2])), c))
+                    cands = [c for _, c in sorted(timed)[:3]]
+                cands = [c for c in cands + [None] if c != cur]
+                best_c, best_t = cur, base
+                for c in cands:
+                    if VERBOSE:
+                        print("    try", obj.tune_key(bp) + "_v4", c, flush=True)
+                    if c is not None and c[2] > 1:
+                        obj.v4_side(c[0])._v4_buffers(bp, c[1], c[2])
+                    obj._tuned_v4[bp] = c
+                    ops.MultiPack.refresh(obj)
+                    t = measure()
+                    if t < best_t - noise:
+                        best_c, best_t = c, t
+                obj._tuned_v4[bp] = best_c
+                ops.MultiPack.refresh(obj)
+                label = obj.tune_key(bp) + "_v4"
+            elif kind == "g":
                 cur = tuple(obj._tuned[bp])
                 v2_now = tuple(obj._tuned_v2[bp])
                 cands = [tuple(c) for c in obj.v2_candidates(bp)]
@@ -159,6 +203,9 @@ def main():
     for kind, obj in knobs:
         if kind == "g":
             out[obj.tune_key(bp)] = list(obj._tuned[bp])
+        elif kind == "g4":
+            c = obj._tuned_v4.get(bp)
+            out[obj.tune_key(bp) + "_v4"] = list(c) if c else [0]
         else:
             out[obj.wg_tune_key(bp)] = [obj._split_tuned[bp], 0, int(obj._mode_tuned.get(bp, 0))]
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
