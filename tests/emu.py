@@ -133,3 +133,103 @@ def emu_wgrad(op, dy, x, dw):
                         if (bits >> k) & 1:
                             dwf[ctab[rid, k] if side else rid, cid if side else ctab[cid, k], tap] = v
     return dw
+
+
+# ---- fourth-generation gather-GEMM (csrc/gemm_v4.hip): bf16 planes in A-operand order, K steps of 32 channels ----
+def bf16_split3(x):
+    """x (float32 array) -> three uint16 arrays of bf16 bit patterns with x == p0 + p1 + p2 exactly (round to nearest
+    even at each level), as split2() does on the device."""
+    planes = []
+    r = np.ascontiguousarray(x, dtype=np.float32)
+    for _ in range(3):
+        u = r.view(np.uint32).astype(np.uint64)
+        h = ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+        planes.append(h.astype(np.uint16))
+        r = (r - (h << 16).astype(np.uint32).view(np.float32)).astype(np.float32)
+    assert not r.any()
+    return planes
+
+
+def bf16_value(bits):
+    return (bits.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+def emu_pack4(side, dense):
+    """hmvae_pack_weights_v4: uint16 [fragment][lane (kk*16 + m)][8], fragment = ((c32*kt + vt)*mtg + tile)*3 + plane at the
+    group's offset g_woff4 (in fragments).  `side` is a layout-4 companion (ops._Side.v4_side)."""
+    g = side.g
+    assert side.layout == 4
+    # the effective matrix per (group, row, listed channel, vt) comes from the v2 emulation's own arithmetic: pack the
+    # SAME tables in the v2 order and re-address
+    wp2 = emu_pack(side, dense)
+    woff4 = _np(side.g_woff4)
+    mtg = g.mt
+    out = np.zeros(max(int(side.wp.numel()), 1), dtype=np.uint16).reshape(-1, 64, 8)
+    for gi in range(g.n_groups):
+        nc4 = int(g.g_nc4[gi])
+        W = wp2[g.g_woff[gi]:g.g_woff[gi] + nc4 * g.kt * mtg * 64].reshape(nc4, g.kt, mtg, 4, 16)   # [c4][vt][tile][kk4][m]
+        for c32 in range(nc4 // 8):
+            for vt in range(g.kt):
+                for tile in range(mtg):
+                    blk = np.zeros((4, 16, 8), dtype=np.float32)              # [kk][m][j]: channel c32*32 + kk*8 + j
+                    for kk in range(4):
+                        for j in range(8):
+                            c = c32 * 32 + kk * 8 + j
+                            blk[kk, :, j] = W[c // 4, vt, tile, c % 4, :]
+                    planes = bf16_split3(blk.reshape(64, 8))
+                    f0 = int(woff4[gi]) + ((c32 * g.kt + vt) * mtg + tile) * 3
+                    for pl in range(3):
+                        out[f0 + pl] = planes[pl]
+    return out
+
+
+def emu_gather4(side, wp4, src, dst, nc=64, split=1, bias=None, leaky=False, accum=False, slope=0.2):
+    """hmvae_gather_gemm_v4 on numpy [rows, bp] operands: units (group, position, nc columns), K steps (c32, item) with the
+    item fastest, cut into `split` parts that are summed in part order."""
+    g = side.g
+    mtg = g.mt
+    R = mtg * 16
+    chan_rows, dst_rows = _np(side.chan_rows), _np(side.dst_rows)
+    bias_idx = _np(side.bias_idx)
+    bias_idx2 = None if getattr(side, "bias_idx2", None) is None else _np(side.bias_idx2)
+    pb_off, pb_len, items, n_pblk, _ = side.items_for(1)
+    pb_off, pb_len, items = _np(pb_off), _np(pb_len), _np(items).reshape(-1, 2)
+    woff4, ntiles = _np(side.g_woff4), _np(side.g_ntiles)
+    bp = src.shape[1]
+    assert bp % nc == 0 and n_pblk == side.n_pos
+    for gi in range(g.n_groups):
+        nc32 = int(g.g_nc4[gi]) // 8
+        rows_src = chan_rows[g.g_choff[gi]:g.g_choff[gi] + nc32 * 32]
+        for p in range(side.n_pos):
+            its = items[pb_off[p]:pb_off[p] + pb_len[p]]
+            nks = nc32 * len(its)
+            for cb in range(bp // nc):
+                cols = slice(cb * nc, (cb + 1) * nc)
+                total = np.zeros((R, nc), dtype=np.float64)
+                for sp in range(split):
+                    part = np.zeros((R, nc), dtype=np.float64)
+                    for ks in range(nks * sp // split, nks * (sp + 1) // split):
+                        c32, it = divmod(ks, len(its))
+                        q, vt = int(its[it, 0]), int(its[it, 1]) & 0xff
+                        B = src[rows_src[c32 * 32:(c32 + 1) * 32] + q * side.src_ts][:, cols].astype(np.float64)   # [32 k][nc]
+                        for tile in range(int(ntiles[gi])):
+                            f0 = int(woff4[gi]) + ((c32 * g.kt + vt) * mtg + tile) * 3
+                            A = sum(bf16_value(wp4[f0 + pl]) for pl in range(3))                 # [lane][8]
+                            A = A.reshape(4, 16, 8).transpose(1, 0, 2).reshape(16, 32)            # [m][k = kk*8 + j]
+                            part[tile * 16:(tile + 1) * 16] += A @ B
+                    total += part
+                for r in range(int(ntiles[gi]) * 16):
+                    dr = dst_rows[gi * R + r]
+                    if dr < 0:
+                        continue
+                    v = total[r]
+                    if bias is not None and bias_idx[gi * R + r] >= 0:
+                        bv = bias[bias_idx[gi * R + r]]
+                        if bias_idx2 is not None and bias_idx2[gi * R + r] >= 0:
+                            bv = 0.5 * (bv + bias[bias_idx2[gi * R + r]])
+                        v = v + bv
+                    if leaky:
+                        v = np.where(v > 0, v, v * slope)
+                    row = dr + p * side.dst_ts
+                    dst[row, cols] = (dst[row, cols] + v) if accum else v
+    return dst

@@ -8,8 +8,29 @@ import torch.nn.functional as F
 from oracle import hmvae_oracle as O
 from hm_vae_amd import ops, planner, topology
 from hm_vae_amd import planner as P
-from emu import emu_pack, emu_gather, emu_wgrad
+from emu import emu_pack, emu_gather, emu_wgrad, emu_pack4, emu_gather4
 from helpers import rel_err
+
+
+def check_v4_tables(side, dense, src, ref_soa_fn, ref, n_rows, bias=None, leaky=False):
+    """The v4 kernel's tables (planner.make_groups_v4, 32-channel K steps, bf16 planes in A-operand order, split K) driven
+    through their numpy emulation must give the oracle's result: both group sizes, unsplit and split three ways."""
+    n = 0
+    for mtw in (1, 2):
+        sd = side.v4_side(mtw)
+        if sd is None:
+            continue
+        g = sd.g
+        assert g.mt == 4 * mtw and (g.g_nc4 % 8 == 0).all()
+        rows = g.row_id[g.row_id >= 0]
+        assert len(set(rows.tolist())) == len(rows) == len(set(side.g.row_id[side.g.row_id >= 0].tolist()))   # every row once
+        wp4 = emu_pack4(sd, dense)
+        for split in (1, 3):
+            out = np.zeros((n_rows, src.shape[1]), dtype=np.float32)
+            emu_gather4(sd, wp4, src, out, nc=64, split=split, bias=bias, leaky=leaky)
+            assert rel_err(ref_soa_fn(out), ref) < 1e-5, (mtw, split)
+            n += 1
+    assert n > 0
 
 
 def to_soa(x):          # (B, C, T) -> [C*T, bp]
@@ -77,6 +98,9 @@ def test_conv_tables_reproduce_oracle(case):
     dxs = np.zeros((cin * T, ops.pad_batch(B)), dtype=np.float32)
     emu_gather(op.bwd, wpb, to_soa(gy), dxs)
     assert rel_err(from_soa(dxs, B, cin, T).numpy(), x.grad.numpy()) < 1e-5
+    check_v4_tables(op.fwd, w.detach().numpy(), to_soa(x.detach()), lambda o: from_soa(o, B, cout, T_out).numpy(),
+                    y.detach().numpy(), cout * T_out, bias=b.detach().numpy())
+    check_v4_tables(op.bwd, w.detach().numpy(), to_soa(gy), lambda o: from_soa(o, B, cin, T).numpy(), x.grad.numpy(), cin * T)
     # backward weight
     dw = np.zeros((cout, cin, K), dtype=np.float32)
     emu_wgrad(op, to_soa(gy), to_soa(x.detach()), dw)
@@ -140,6 +164,10 @@ def test_conv_behind_upsample_unpool_reproduces_oracle(case):
     dxs = np.zeros((n_c * ch * Tc, ops.pad_batch(B)), dtype=np.float32)
     emu_gather(op.bwd, emu_pack(op.bwd, w.detach().numpy()), to_soa(gy), dxs)
     assert rel_err(from_soa(dxs, B, n_c * ch, Tc).numpy(), xc.grad.numpy()) < 1e-5
+    check_v4_tables(op.fwd, w.detach().numpy(), to_soa(xc.detach()), lambda o: from_soa(o, B, cout, T).numpy(),
+                    y.detach().numpy(), cout * T, bias=b.detach().numpy())
+    check_v4_tables(op.bwd, w.detach().numpy(), to_soa(gy), lambda o: from_soa(o, B, n_c * ch, Tc).numpy(),
+                    xc.grad.numpy(), n_c * ch * Tc)
     dw = np.zeros((cout, cin, K), dtype=np.float32)
     emu_wgrad(op, to_soa(gy), to_soa(U.detach()), dw)              # the weight gradient keeps the conv's own input
     assert rel_err(dw, (w.grad * mask).numpy()) < 1e-5
@@ -188,6 +216,10 @@ def test_conv_followed_by_pool_reproduces_oracle(case):
     dxs = np.zeros((cin * T, ops.pad_batch(B)), dtype=np.float32)
     emu_gather(op.bwd, emu_pack(op.bwd, w.detach().numpy()), to_soa(pre.grad), dxs)
     assert rel_err(from_soa(dxs, B, cin, T).numpy(), x.grad.numpy()) < 1e-5
+    check_v4_tables(op.fwd, w.detach().numpy(), to_soa(x.detach()), lambda o: from_soa(o, B, n_p * co, T_out).numpy(),
+                    a.detach().numpy(), n_p * co * T_out, bias=b.detach().numpy(), leaky=True)
+    check_v4_tables(op.bwd, w.detach().numpy(), to_soa(pre.grad), lambda o: from_soa(o, B, cin, T).numpy(), x.grad.numpy(),
+                    cin * T)
     dw = np.zeros((cout, cin, K), dtype=np.float32)
     # the rows a pool group averages share their gradient: the deduplicated weight gradient takes the pooled one
     emu_wgrad(op, to_soa(pre.grad if op.wg_pooled_dz else y.grad), to_soa(x.detach()), dw)
