@@ -173,7 +173,8 @@ def main():
                 label = obj.tune_key(bp)
             else:
                 cur = (obj._split_tuned[bp], obj._mode_tuned.get(bp, 0))
-                modes = [0] + ([1] if obj.lds_eligible() else []) + ([2] if (ops.WGRAD_BF3 and obj.bf3_eligible()) else [])
+                modes = [0] + ([1] if obj.lds_eligible() else []) + ([2] if (ops.WGRAD_BF3 and obj.bf3_eligible()) else []) + \
+                    ([3] if (ops.WGRAD_BF3 and obj.lds_eligible() and obj.pair_eligible()) else [])
                 splits = [c for c in obj.split_candidates(bp) if not a.fast or c in (1, 2, 3, 4, 6, 8)]
                 cands = [(c, m) for m in modes for c in splits if (c, m) != cur]
                 best_c, best_t = cur, base
