@@ -23,6 +23,8 @@ def build(force=False, verbose=True):
     extra = ["-DHMVAE_STAMP"] if os.environ.get("HMVAE_STAMP") else []      # diagnostic build: in-kernel s_memtime stamps
     if os.environ.get("HMVAE_ABLATE"):                                        # diagnostic build: timing ablations of the v3 kernel
         extra.append("-DHMVAE_ABLATE")
+    if os.environ.get("HMVAE_CXXFLAGS"):                                      # experiments: extra -D flags for every file
+        extra += os.environ["HMVAE_CXXFLAGS"].split()
     if extra:
         force = True
     srcs = [os.path.join(CSRC, s) for s in SOURCES]

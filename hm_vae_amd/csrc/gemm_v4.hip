@@ -8,8 +8,9 @@
 // limit).  Here
 //   * a float is the exact sum of three bf16 numbers; six of the nine cross products carry everything above 2^-24 of
 //     a product and run as v_mfma_f32_16x16x32_bf16 (fp32 accumulation): 96 cycles for K = 32 where fp32 needs 256;
-//   * the weights are split once per step by the pack kernel, straight into A-operand order (16 bytes per lane and
-//     plane, read from L2 by the one wave that owns the row tile: mtw*3 loads per K step);
+//   * the weights are packed once per step straight into A-operand order as fp32 (32 bytes per lane and row tile, read
+//     from L2 by the one wave that owns the tile) and split into their planes in registers: 4 instead of 6 bytes per
+//     weight through the load path -- the weight fragments are the larger half of a K step's bytes;
 //   * the activations are split once per workgroup on their way into LDS (row-major bf16 planes, 16-byte global loads,
 //     8-byte LDS stores) and shared by the 4 waves, i.e. by 4*mtw row tiles; the B operands come out of LDS already
 //     transposed (ds_read_b64_tr_b16: lane (n, kk) gets rows 8kk .. 8kk+7 of column n), so the batch-innermost layout
@@ -49,6 +50,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifndef V4_R14
+#define V4_R14 6
+#endif
 constexpr int V4_MAX_ITEMS = 256;
 constexpr int V4_MAX_NC32 = 32;
 
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
     const unsigned rd_base = ((8u * kk + q) * PITCH + (p << 3)) | (chunk_swz<NC>(8u * kk + q) << 5);
     // A fragments
     const char* __restrict__ wbase = (const char*)d.wp4 + (size_t)d.g_woff4[g] * 1024;
-    const unsigned lane_a = (unsigned)(wave * MTW * 3) * 1024u + (unsigned)lane * 16u;
+    const unsigned lane_a = (unsigned)(wave * MTW) * 2048u + (unsigned)lane * 16u;
     const unsigned kt = (unsigned)d.kt;
 
     f32x4 acc[MTW][NT];
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
     // previous sub-step -- is being refilled.  The loads of a K step take 1-2 us under load; its MFMAs 0.2-0.7 us.
     int c32 = k0 / (nitems > 0 ? nitems : 1), it = k0 - c32 * nitems, ks = k0;
     f32x4 rb[R][NPASS];
-    bf16x8 ra[R][MTW][3];
+    f32x4 ra[R][MTW][2];                  // a row tile's A fragment: 8 consecutive channels of row m per lane, fp32
     auto advance = [&]() {
         const bool more = ks + 1 < k1;
         const int ni = it + 1;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
         c32 = more ? (wrap ? c32 + 1 : c32) : c32;
         ks = more ? ks + 1 : ks;
     };
-    auto fetch = [&](f32x4 (&b)[NPASS], bf16x8 (&a)[MTW][3], bool with_a) {
+    auto fetch = [&](f32x4 (&b)[NPASS], f32x4 (&a)[MTW][2], bool with_a) {
         const int2 item = *(const int2*)(lds_items + 2 * it);
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
@@ -173,11 +177,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
             b[i] = *(const f32x4*)(sbase + (ro + (unsigned)item.x + col_b));
         }
         if (with_a) {
-            const unsigned fo = ((unsigned)c32 * kt + (unsigned)item.y) * (unsigned)(MTG * 3 * 1024) + lane_a;
+            const unsigned fo = ((unsigned)c32 * kt + (unsigned)item.y) * (unsigned)(MTG * 2048) + lane_a;
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[mt][pl] = *(const bf16x8*)(wbase + (fo + (unsigned)((mt * 3 + pl) * 1024)));
+                for (int h = 0; h < 2; ++h) a[mt][h] = *(const f32x4*)(wbase + (fo + (unsigned)(mt * 2048 + h * 1024)));
         }
         advance();
     };
@@ -192,8 +196,27 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
             *(u32x2*)(img + 2 * PLB + st_off[i]) = (u32x2){h2a, h2b};
         }
     };
-    auto compute = [&](const char* img, const bf16x8 (&a)[MTW][3]) {
+    auto compute = [&](const char* img, const f32x4 (&af)[MTW][2]) {
         typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
+        // the weights' three planes are made here, in registers (44 vector instructions per tile and K step, beside
+        // 24-96 MFMAs): 4 instead of 6 bytes per weight through the load path, and nothing for the pack to split
+        bf16x8 a[MTW][3];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            u32x4 w0, w1, w2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                unsigned p0, p1, p2, q0, q1, q2;
+                split2(af[mt][h][0], af[mt][h][1], p0, p1, p2);
+                split2(af[mt][h][2], af[mt][h][3], q0, q1, q2);
+                w0[2 * h] = p0; w0[2 * h + 1] = q0;
+                w1[2 * h] = p1; w1[2 * h + 1] = q1;
+                w2[2 * h] = p2; w2[2 * h + 1] = q2;
+            }
+            a[mt][0] = __builtin_bit_cast(bf16x8, w0);
+            a[mt][1] = __builtin_bit_cast(bf16x8, w1);
+            a[mt][2] = __builtin_bit_cast(bf16x8, w2);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             bf16x8 b[3];
@@ -327,15 +350,16 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
     STAMP4(6);
 }
 
-// ---- weight pack: effective matrix -> three bf16 planes in A-operand order ----
+// ---- weight pack: effective matrix -> fp32 fragments in A-operand order ----
 // block = (group, row tile, 32 channels): 512 (row, channel) pairs, two neighbouring channels per thread -- thread (m,
-// kk, jh) owns row m and channels 8kk + 2jh, +1 of the block, i.e. one 32-bit word of lane (m, kk)'s 16-byte piece per
-// virtual tap and plane.  The (<= 16) real taps of both pairs stay in registers; virtual taps are produced 8 at a time
-// into a 24 KB LDS image ([vt][plane][lane][16 bytes] = the output order) and leave as whole 1 KB fragments.
+// kk, jh) owns row m and channels 8kk + 2jh, +1 of the block, i.e. 8 bytes of lane (m, kk)'s 32-byte piece per virtual
+// tap.  The (<= 16) real taps of both pairs stay in registers; virtual taps are produced 8 at a time into a 16 KB LDS
+// image ([vt][channel half][lane][16 bytes] = the output order: a wave reads a fragment as two whole 1 KB rows) and leave as
+// whole 2 KB fragments.
 constexpr int P4_VC = 8;                       // virtual taps per LDS image
 
 __global__ __launch_bounds__(256) void pack4_kernel(const hmvae_pack_op* __restrict__ ops, int n_ops) {
-    extern __shared__ __attribute__((aligned(16))) char simg[];   // [P4_VC][3][64 lanes][16 B], then C[kt][16] floats
+    extern __shared__ __attribute__((aligned(16))) char simg[];   // [P4_VC][64 lanes][8 floats], then C[kt][16] floats
     int oi;
     {
         const int lane = threadIdx.x & 63;
@@ -366,13 +390,14 @@ __global__ __launch_bounds__(256) void pack4_kernel(const hmvae_pack_op* __restr
         cid[e] = o.chan_id[o.g_choff[g] + c0 + e];
         bits[e] = (rid >= 0 && cid[e] >= 0) ? o.pair_ok[o.g_okoff[g] + r * (nc4 * 4) + c0 + e] : 0u;
     }
-    unsigned* img = (unsigned*)simg;
-    const unsigned my_word = (unsigned)((kk * 16 + m) * 4 + jh);   // dword of this thread inside a 1 KB fragment
+    f32x2* img = (f32x2*)simg;
+    // 8-byte slot of this thread inside a 2 KB fragment: [half of the 8 channels][lane (kk, m)][4 floats]
+    const unsigned my_pair = (unsigned)((jh >> 1) * 128 + (kk * 16 + m) * 2 + (jh & 1));
     char* outg = (char*)o.packed + (size_t)o.g_woff[g] * 1024;
     const bool folded = o.fold_taps != nullptr;
     const int kr = folded ? o.fold_kt : 0;
     float t[2][16];
-    float* ct = (float*)(simg + P4_VC * 3072);                      // [kt][16]
+    float* ct = (float*)(simg + P4_VC * 2048);                      // [kt][16]
     const float* psrc[2] = {o.dense, o.dense};
     if (folded) {
         const int nf = o.fold_nf;
@@ -415,7 +440,7 @@ __global__ __launch_bounds__(256) void pack4_kernel(const hmvae_pack_op* __restr
         __syncthreads();                                           // C visible (first pass) / previous image copied out
         for (int vl = 0; vl < nv; ++vl) {
             const int vt = v0 + vl;
-            float v[2];
+            f32x2 v;
             if (folded) {
                 const f32x4* c = (const f32x4*)(ct + vt * 16);
                 const f32x4 q0 = c[0], q1 = c[1], q2 = c[2], q3 = c[3];
@@ -431,18 +456,14 @@ __global__ __launch_bounds__(256) void pack4_kernel(const hmvae_pack_op* __restr
 #pragma unroll
                 for (int e = 0; e < 2; ++e) v[e] = bits[e] ? psrc[e][(size_t)vt * o.tap_stride] : 0.f;
             }
-            unsigned h0, h1, h2;
-            split2(v[0], v[1], h0, h1, h2);
-            img[(vl * 3 + 0) * 256 + my_word] = h0;
-            img[(vl * 3 + 1) * 256 + my_word] = h1;
-            img[(vl * 3 + 2) * 256 + my_word] = h2;
+            img[vl * 256 + my_pair] = v;
         }
         __syncthreads();
-        // fragment ((c32*kt + vt)*mtg + tg)*3 + pl: the three planes of one vt are 3 KB in a row
-        for (int i = tid; i < nv * 192; i += 256) {
-            const int vl = i / 192, w16 = i - vl * 192;
-            const size_t frag0 = ((size_t)(c32 * kt + v0 + vl) * mtg + tg) * 3;
-            *(u32x4*)(outg + frag0 * 1024 + (size_t)w16 * 16) = *(const u32x4*)(simg + (size_t)(vl * 192 + w16) * 16);
+        // fragment (c32*kt + vt)*mtg + tg, 2 KB each
+        for (int i = tid; i < nv * 128; i += 256) {
+            const int vl = i >> 7, w16 = i & 127;
+            const size_t frag = (size_t)(c32 * kt + v0 + vl) * mtg + tg;
+            *(u32x4*)(outg + frag * 2048 + (size_t)w16 * 16) = *(const u32x4*)(simg + (size_t)i * 16);
         }
     }
 }
@@ -450,7 +471,7 @@ __global__ __launch_bounds__(256) void pack4_kernel(const hmvae_pack_op* __restr
 template <int MTW, int NT>
 int launch4(const hmvae_gemm4_desc* d, hipStream_t s) {
     // K steps in flight per wave: enough to cover ~2 us of load latency with the MFMA time of a step (96 cycles per tile pair)
-    constexpr int R = MTW * NT <= 4 ? 6 : (MTW * NT <= 8 ? 4 : 3);
+    constexpr int R = MTW * NT <= 4 ? V4_R14 : (MTW * NT <= 8 ? 4 : 3);
     constexpr int NC = NT * 16;
     size_t lds = 2 * 3 * 32 * NC * 2 + V4_MAX_NC32 * 32 * 4 + 2 * V4_MAX_ITEMS * 4 + 16;
     const size_t tile = (size_t)MTW * 64 * NC * 4;
@@ -495,7 +516,7 @@ extern "C" int hmvae_gather_gemm_v4(const hmvae_gemm4_desc* d, hmvae_stream_t st
 extern "C" int hmvae_pack_weights_v4(const hmvae_pack_op* ops_dev, int32_t n_ops, int32_t total_blocks, int32_t max_kt,
                                      hmvae_stream_t stream) {
     if (!ops_dev || n_ops <= 0 || n_ops > 64 || total_blocks <= 0 || max_kt <= 0) return HMVAE_ERR_ARG;
-    const size_t lds = (size_t)P4_VC * 3072 + (size_t)max_kt * 64;
+    const size_t lds = (size_t)P4_VC * 2048 + (size_t)max_kt * 64;
     if (lds > 64 * 1024) return HMVAE_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack4_kernel, dim3((unsigned)total_blocks), dim3(256), lds, (hipStream_t)stream, ops_dev, n_ops);
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;

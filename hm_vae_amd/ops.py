@@ -191,7 +191,7 @@ class _Side:
             g = groups
             assert (g.g_nc4 % 8 == 0).all()
             self.g_nc32 = _dev((g.g_nc4 // 8).astype(np.int32), device)
-            frags = (g.g_nc4 // 8).astype(np.int64) * g.kt * g.mt * 3
+            frags = (g.g_nc4 // 8).astype(np.int64) * g.kt * g.mt * 2          # in KB: a fragment is 2 KB of fp32
             woff4 = np.concatenate([[0], np.cumsum(frags)[:-1]]).astype(np.int64)
             assert int(frags.sum()) * 1024 < 2 ** 31
             self.g_woff4 = _dev(woff4.astype(np.int32), device)

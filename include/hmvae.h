@@ -158,9 +158,10 @@ int hmvae_gather_gemm_v3(const hmvae_conv3_desc* desc, hmvae_stream_t stream);
  * (round to nearest at each level); of the nine cross products the six of weight >= 2^-16 carry
  * everything above 2^-24 of a product and run as v_mfma_f32_16x16x32_bf16 with fp32 accumulation --
  * 96 issue cycles where v_mfma_f32_16x16x4_f32 needs 256 for the same K.
- *   weights     : split ONCE per step by hmvae_pack_weights_v4 into MFMA A-operand order
- *                 wp4[group][c32 < nc32][tap < kt][tile < mtg][plane < 3][lane (m, kk)][8 bf16],
- *                 channel of (lane, j) = c32*32 + kk*8 + j of the group's list (lists are padded to 32);
+ *   weights     : packed once per step by hmvae_pack_weights_v4 into MFMA A-operand order, fp32:
+ *                 wp4[group][c32 < nc32][tap < kt][tile < mtg][h < 2][lane (m, kk)][4 floats] (2 KB per fragment),
+ *                 channel of (h, lane, j) = c32*32 + kk*8 + 4h + j of the group's list (lists are padded to 32);
+ *                 the wave that owns a row tile splits its fragment into the three planes in registers;
  *   activations : stay fp32 in HBM ([rows][bp]); a workgroup (4 waves) stages the 32 rows of a K step
  *                 (32 channels of one source position) for its 64 / 128 batch columns into LDS as three
  *                 row-major bf16 planes (one split per element per workgroup) and every wave takes
@@ -176,7 +177,7 @@ int hmvae_gather_gemm_v3(const hmvae_conv3_desc* desc, hmvae_stream_t stream);
 typedef struct {
     const float* src;
     float* dst;
-    const uint16_t* wp4;     /* packed bf16 planes (hmvae_pack_weights_v4) */
+    const uint16_t* wp4;     /* packed fragments (hmvae_pack_weights_v4) */
     const float* bias;
     const int32_t* bias_idx; /* [n_groups*mtg*16], as v2 */
     const int32_t* bias_idx2;/* NULL or as v2 */
@@ -350,7 +351,7 @@ int hmvae_pack_weights_multi(const hmvae_pack_op* ops_dev, int32_t n_ops, int32_
                              hmvae_stream_t stream);
 
 /* Weight packs for hmvae_gather_gemm_v4: the effective matrix of a hmvae_pack_op -- mask, virtual taps, merged
- * rows / channels: same tables, lists padded to 32 channels, g_nc4 = 8 * nc32 -- split into three bf16 planes in the
+ * rows / channels: same tables, lists padded to 32 channels, g_nc4 = 8 * nc32 -- as fp32 fragments in the
  * layout above.  One workgroup per (group, row tile, 32 channels); op i owns the blocks block_start .. block_start +
  * n_groups * mt * max_nc4 / 8 (mt = tiles per group, g_woff in 1 KB fragments, packed = the uint16 buffer). */
 int hmvae_pack_weights_v4(const hmvae_pack_op* ops_dev, int32_t n_ops, int32_t total_blocks, int32_t max_kt,

@@ -155,8 +155,8 @@ def bf16_value(bits):
 
 
 def emu_pack4(side, dense):
-    """hmvae_pack_weights_v4: uint16 [fragment][lane (kk*16 + m)][8], fragment = ((c32*kt + vt)*mtg + tile)*3 + plane at the
-    group's offset g_woff4 (in fragments).  `side` is a layout-4 companion (ops._Side.v4_side)."""
+    """hmvae_pack_weights_v4: float32 [fragment][h][lane (kk*16 + m)][4] (channel 8kk + 4h + j), fragment = (c32*kt + vt)*mtg
+    + tile at the group's offset g_woff4 (in KB; a fragment is 2 KB).  `side` is a layout-4 companion (ops._Side.v4_side)."""
     g = side.g
     assert side.layout == 4
     # the effective matrix per (group, row, listed channel, vt) comes from the v2 emulation's own arithmetic: pack the
@@ -164,7 +164,7 @@ def emu_pack4(side, dense):
     wp2 = emu_pack(side, dense)
     woff4 = _np(side.g_woff4)
     mtg = g.mt
-    out = np.zeros(max(int(side.wp.numel()), 1), dtype=np.uint16).reshape(-1, 64, 8)
+    out = np.zeros(max(int(side.wp.numel()) // 2, 1), dtype=np.float32).reshape(-1, 2, 64, 4)
     for gi in range(g.n_groups):
         nc4 = int(g.g_nc4[gi])
         W = wp2[g.g_woff[gi]:g.g_woff[gi] + nc4 * g.kt * mtg * 64].reshape(nc4, g.kt, mtg, 4, 16)   # [c4][vt][tile][kk4][m]
@@ -176,15 +176,12 @@ def emu_pack4(side, dense):
                         for j in range(8):
                             c = c32 * 32 + kk * 8 + j
                             blk[kk, :, j] = W[c // 4, vt, tile, c % 4, :]
-                    planes = bf16_split3(blk.reshape(64, 8))
-                    f0 = int(woff4[gi]) + ((c32 * g.kt + vt) * mtg + tile) * 3
-                    for pl in range(3):
-                        out[f0 + pl] = planes[pl]
+                    out[int(woff4[gi]) // 2 + (c32 * g.kt + vt) * mtg + tile] = blk.reshape(64, 2, 4).transpose(1, 0, 2)
     return out
 
 
 def emu_gather4(side, wp4, src, dst, nc=64, split=1, bias=None, leaky=False, accum=False, slope=0.2):
-    """hmvae_gather_gemm_v4 on numpy [rows, bp] operands: units (group, position, nc columns), K steps (c32, item) with the
+    """hmvae_gather_gemm_v4 on numpy [rows, bp] operands (wp4 from emu_pack4): units (group, position, nc columns), K steps (c32, item) with the
     item fastest, cut into `split` parts that are summed in part order."""
     g = side.g
     mtg = g.mt
@@ -213,8 +210,10 @@ def emu_gather4(side, wp4, src, dst, nc=64, split=1, bias=None, leaky=False, acc
                         q, vt = int(its[it, 0]), int(its[it, 1]) & 0xff
                         B = src[rows_src[c32 * 32:(c32 + 1) * 32] + q * side.src_ts][:, cols].astype(np.float64)   # [32 k][nc]
                         for tile in range(int(ntiles[gi])):
-                            f0 = int(woff4[gi]) + ((c32 * g.kt + vt) * mtg + tile) * 3
-                            A = sum(bf16_value(wp4[f0 + pl]) for pl in range(3))                 # [lane][8]
+                            frag = wp4[int(woff4[gi]) // 2 + (c32 * g.kt + vt) * mtg + tile]      # [h][lane][4] fp32
+                            frag = np.ascontiguousarray(frag.transpose(1, 0, 2)).reshape(64, 8)
+                            planes = bf16_split3(frag)                # what the owning wave does in registers: exact
+                            A = sum(bf16_value(pl) for pl in planes)
                             A = A.reshape(4, 16, 8).transpose(1, 0, 2).reshape(16, 32)            # [m][k = kk*8 + j]
                             part[tile * 16:(tile + 1) * 16] += A @ B
                     total += part
