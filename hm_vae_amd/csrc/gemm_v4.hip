@@ -58,6 +58,10 @@ constexpr int V4_MAX_NC32 = 32;
 
 // x = p0 + p1 + p2 exactly, round-to-nearest-even at each level; returns the three packed pairs of (x0, x1)
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& h0, unsigned& h1, unsigned& h2) {
+#ifdef V4_ABL_NOSPLIT            // timing ablation (wrong results): no arithmetic behind the planes
+    h0 = __float_as_uint(x0); h1 = __float_as_uint(x1); h2 = h0 ^ h1;
+    return;
+#endif
     f32x2 v = {x0, x1};
     h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
     f32x2 r = {x0 - __uint_as_float(h0 << 16), x1 - __uint_as_float(h0 & 0xffff0000u)};
@@ -234,7 +238,13 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
             for (int t = 0; t < 6; ++t)
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt)
+                    {
+#ifdef V4_ABL_NOMFMA             // timing ablation (wrong results): the operands are consumed by one cheap instruction
+                    acc[mt][nt][0] += __builtin_bit_cast(f32x4, a[mt][PA[t]])[0] + __builtin_bit_cast(f32x4, b[PB[t]])[0];
+#else
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][PA[t]], b[PB[t]], acc[mt][nt], 0, 0, 0);
+#endif
+                }
         }
     };
     const int n = k1 - k0;
@@ -250,7 +260,9 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
             for (int u = 0; u < R; ++u) {
                 char* img = lds + ((cnt & 1) ? BUFB : 0u);
                 stash(img, rb[u]);
+#ifndef V4_ABL_NOBAR             // timing ablation (wrong results): no workgroup barrier per K step
                 __syncthreads();
+#endif
                 fetch(rb[(u + D) % R], ra[(u + D) % R], M);
                 if (M) compute(img, ra[u]);
                 ++cnt;
