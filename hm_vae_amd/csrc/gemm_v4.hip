@@ -40,7 +40,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     do {                                                                                           \
         if (d.debug && threadIdx.x == 0) {                                                         \
             unsigned long long t_;                                                                 \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
             d.debug[(size_t)blockIdx.x * 8 + (i)] = t_;                                            \
         }                                                                                          \
     } while (0)

@@ -1,5 +1,5 @@
 """Dev tool (GPU box, library built with HMVAE_STAMP=1): where a workgroup of the v4 gather-GEMM spends its life.
-Stamps (s_memtime, 100 MHz ticks -> printed in us): 0 start, 1 tables in LDS, 2 ring filled (loop entry), 3 loop end,
+Stamps (s_memrealtime: one 100 MHz clock for the whole chip, 10 ns ticks -> printed in us): 0 start, 1 tables in LDS, 2 ring filled (loop entry), 3 loop end,
 4 part stored + drained, 5 counter returned, 6 end.  usage: python tools/stamp_v4.py layer side mtw nc split"""
 import sys, os
 import numpy as np, torch
@@ -50,6 +50,12 @@ for i, l in enumerate(lab):
     col = d[:, i][t[:, i + 1] > 0]
     if len(col):
         print("  %-12s mean %6.2f  p50 %6.2f  p90 %6.2f us  (n %d)" % (l, col.mean(), np.median(col), np.percentile(col, 90), len(col)))
-life = (np.where(t[:, 6] > 0, t[:, 6], t[:, 5]) - t[:, 0]) * tick
-print("  workgroup life mean %.2f p90 %.2f us; start spread: p50 %.1f p90 %.1f max %.1f us after the first" % (
-    life.mean(), np.percentile(life, 90), np.median(t[:, 0] - t0) * tick, np.percentile(t[:, 0] - t0, 90) * tick, (t[:, 0].max() - t0) * tick))
+end = np.where(t[:, 6] > 0, t[:, 6], t[:, 5])
+life = (end - t[:, 0]) * tick
+st = np.sort(t[:, 0] - t0) * tick
+print("  workgroup life mean %.2f p90 %.2f us; starts after the first: p10 %.1f p50 %.1f p75 %.1f p90 %.1f max %.1f us; last end %.1f us" % (
+    life.mean(), np.percentile(life, 90), *[np.percentile(st, q) for q in (10, 50, 75, 90)], st.max(), (end.max() - t0) * tick))
+# how many workgroups are alive at once (sampled every 2 us)
+for ts in np.arange(0, (end.max() - t0) * tick, 4.0):
+    alive = int(((t[:, 0] - t0) * tick <= ts).sum() - ((end - t0) * tick <= ts).sum())
+    print("    t=%5.1f us: %4d workgroups alive" % (ts, alive))
