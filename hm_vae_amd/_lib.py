@@ -138,6 +138,7 @@ _SIGS = {
     "hmvae_split_bf16x3": ([_ptr, _ptr, _i64, _i64, _ptr], _i32),
     "hmvae_motion_batch": ([_ptr, _i64, _ptr, _ptr, _ptr, _i32, _i32, _i32] + [_ptr] * 7 + [_ptr], _i32),
     "hmvae_traj_loss_finalize": ([_ptr, _i32, _f32, _f32, _f32, _ptr, _ptr], _i32),
+    "hmvae_keyframe_root_loss": ([_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _f32, _ptr, _ptr, C.POINTER(_i32), _ptr], _i32),
     "hmvae_adam_step": ([_ptr, _i32, _i64, _ptr, _ptr, _f32, _f32, _f32, _f32, _ptr], _i32),
 }
 

@@ -607,6 +607,65 @@ extern "C" int hmvae_traj_loss_finalize(const float* partial, int32_t n_blocks, 
     return LAUNCH_OK();
 }
 
+// ---------------- key-frame root loss of the test-time optimisation loop (seq_two_hier_sa_vae.py:1031-1045, :1376-1389) ----------------
+// cal_key_frame_root_loss as released: the "key frames" are the indices j at which row 0 of the window's (T, 24) mask is
+// non-zero -- i.e. the JOINTS observed in frame 0, used as FRAME indices 0..23 (the comment there says otherwise; the code
+// is what is restated).  pred_root_trans[t] = root pose + sum_{s=1..t} (mean_c + std_c * v[s]) (gen_motion_w_trajectory
+// :486-499; the root pose is the constant root offset and cancels), so for consecutive selected j' < j
+//     e = sum_{s=j'+1..j} (mean_c + std_c * v[s]) - (gt[j] - gt[j']),   L = sum e^2 / N,   dL/dv[s] = g * std_c * e(s)
+// with e(s) the term of the interval that holds s (0 outside every interval), g = 2 w / N, N = 3 * sum_b (K_b - 1) (host).
+// One thread per (component c, window b); rows c*T + t (v, gt), j*T (mask: joint j at frame 0), batch innermost.
+constexpr int KF_MAX = 24;
+__global__ __launch_bounds__(64) void keyframe_root_loss_kernel(const float* __restrict__ v, const float* __restrict__ gt,
+                                                                 const float* __restrict__ mask,
+                                                                 const float* __restrict__ mean3,
+                                                                 const float* __restrict__ std3, int T, int B, int bp,
+                                                                 float g, float* __restrict__ dv, float* __restrict__ partial) {
+    const int chunks = bp >> 6;
+    const int c = blockIdx.x / chunks;
+    const int b = (blockIdx.x - c * chunks) * 64 + threadIdx.x;
+    const float sd = std3[c], mu = mean3[c];
+    const size_t base = (size_t)c * T * bp + b;
+    const int nj = T < KF_MAX ? T : KF_MAX;
+    float sum = 0.f;
+    for (int t = 0; t < T; ++t) dv[base + (size_t)t * bp] = 0.f;
+    if (b < B) {
+        float acc = 0.f;                 // de-standardised running sum up to frame j
+        int jp = -1;                     // previous selected index
+        float accp = 0.f, gtp = 0.f;
+        for (int j = 0; j < nj; ++j) {
+            if (j >= 1) acc += mu + sd * v[base + (size_t)j * bp];
+            if (mask[(size_t)j * T * bp + b] != 0.f) {
+                const float gj = gt[base + (size_t)j * bp];
+                if (jp >= 0) {
+                    const float e = (acc - accp) - (gj - gtp);
+                    sum += e * e;
+                    const float ge = g * sd * e;
+                    for (int s = jp + 1; s <= j; ++s) dv[base + (size_t)s * bp] = ge;
+                }
+                jp = j;
+                accp = acc;
+                gtp = gj;
+            }
+        }
+    }
+    sum = wave_sum(sum);
+    if (threadIdx.x == 0) partial[blockIdx.x] = sum;
+}
+
+extern "C" int hmvae_keyframe_root_loss(const float* v, const float* gt, const float* mask, const float* mean3,
+                                        const float* std3, int32_t T, int32_t B, int32_t bp, float grad_scale, float* dv,
+                                        float* partial, int32_t* n_blocks_out, hmvae_stream_t stream) {
+    if (bp <= 0 || (bp & 63) || B <= 0 || B > bp || T <= 0) return HMVAE_ERR_ARG;
+    const int n_blocks = 3 * (bp >> 6);
+    if (n_blocks_out) *n_blocks_out = n_blocks;
+    if (!v && !gt && !mask && !dv && !partial) return HMVAE_OK;          // size query
+    if (!v || !gt || !mask || !mean3 || !std3 || !dv || !partial) return HMVAE_ERR_ARG;
+    hipLaunchKernelGGL(keyframe_root_loss_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, v, gt, mask, mean3, std3, T,
+                       B, bp, grad_scale, dv, partial);
+    return LAUNCH_OK();
+}
+
 // ---------------- batch assembly from a device-resident dataset (utils_motion_vae.py:124-187) ----------------
 // frames: the packed T_i x 579 sequences, back to back.  One workgroup builds MB_FRAMES consecutive frames of one clip:
 // every source column is read once (coalesced) and lands in the 7 output tensors of the reference's batch tuple.

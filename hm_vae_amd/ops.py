@@ -1355,6 +1355,21 @@ def traj_loss(v, g, std3, T, B, bp, grad_v, grad_t, dv, partial):
     return nb.value
 
 
+def keyframe_root_loss_blocks(T, B, bp):
+    nb = C.c_int32(0)
+    _lib.check(_lib.load().hmvae_keyframe_root_loss(None, None, None, None, None, T, B, bp, 0.0, None, None, C.byref(nb), None),
+               "keyframe_root_loss")
+    return nb.value
+
+
+def keyframe_root_loss(v, gt, mask, mean3, std3, T, B, bp, grad_scale, dv, partial):
+    nb = C.c_int32(0)
+    _lib.check(_lib.load().hmvae_keyframe_root_loss(_lib.ptr(v), _lib.ptr(gt), _lib.ptr(mask), _lib.ptr(mean3), _lib.ptr(std3),
+                                                    T, B, bp, float(grad_scale), _lib.ptr(dv), _lib.ptr(partial), C.byref(nb),
+                                                    _lib.stream()), "keyframe_root_loss")
+    return nb.value
+
+
 def traj_loss_finalize(partial, n_blocks, inv_n, w_v, w_t, out9):
     _lib.check(_lib.load().hmvae_traj_loss_finalize(_lib.ptr(partial), n_blocks, inv_n, w_v, w_t, _lib.ptr(out9),
                                                     _lib.stream()), "traj_loss_finalize")

@@ -17,7 +17,11 @@ the regulariser's anchor) and `restore()` puts them back, so the model is unchan
 
 The released routine cannot run (stale call signatures), so its parity is pinned against the CPU oracle's
 restatement of the same loop only (`OracleVAE.refine_forward`), not against reference outputs: "parity unpinned".
-The trajectory term (`optimize_trajectory`, :1376-1386) is not built.
+The trajectory term (`optimize_trajectory`, :1376-1389): the decoded window's joint positions go through the frozen
+TrajectoryModel (standardise -> encoder -> root velocity), the velocities are accumulated into a root trajectory and its
+differences between "key frames" are held against the ground truth's (cal_key_frame_root_loss :1031-1045, restated AS
+RELEASED: see hmvae_keyframe_root_loss in include/hmvae.h); its gradient reaches the latents through the trajectory encoder's
+data-gradient chain (traj_engine.backward_input), the standardisation, the FK / lift backward and the decoder.
 """
 import os
 
@@ -34,7 +38,10 @@ DECODER_PHASE_AFTER = 50           # seq_two_hier_sa_vae.py:1393 `prev_epochs`
 class LatentRefiner:
     """One batch of windows.  target_rot_mat (B,T,24,3,3), mask (B,T,24) -- 1 where the frame/joint is observed."""
 
-    def __init__(self, model, hp, target_rot_mat, mask, z_shallow=None, z_deep=None, use_graph=None):
+    def __init__(self, model, hp, target_rot_mat, mask, z_shallow=None, z_deep=None, use_graph=None,
+                 trajectory_model=None, root_trans=None):
+        """trajectory_model: the trained TrajectoryModel (hm_vae_amd.trajectory_pred_model, on the device) and root_trans
+        (B,T,3) the windows' ground-truth root translation -- both needed when hp['optimize_trajectory'] is set."""
         self.model, self.hp = model, hp
         # an iteration is ~35 (latent phase) / ~75 (decoder phase) launches of a few microseconds each at the reference's
         # batch of one window: replayed from a hipGraph per phase (the phase's first iteration runs eagerly -- it creates
@@ -45,14 +52,15 @@ class LatentRefiner:
         self._graphs, self._eager_done = {}, {False: 0, True: 0}
         self.eng = eng = model.engine()
         p, dev = eng.p, eng.device
-        if hp.get('optimize_trajectory', False):
-            raise NotImplementedError("optimize_trajectory (seq_two_hier_sa_vae.py:1376-1386) is not built")
         B, T = target_rot_mat.shape[0], target_rot_mat.shape[1]
         if T != p.T:
             raise ValueError("window length %d != train_seq_len %d" % (T, p.T))
         self.B, self.T = B, T
         self.w = w = eng.workspace(B)
         bp = w["bp"]
+        self.traj = None
+        if hp.get('optimize_trajectory', False):
+            self._init_trajectory(trajectory_model, dev, B, T, bp)
         if "MK" not in w:
             w["MK"] = torch.zeros(24 * T, bp, device=dev)
             nb = ops.l2_anchor_blocks()
@@ -76,9 +84,33 @@ class LatentRefiner:
             self.gen_opt_for_decoder = HipAdam([eng.params[n] for n in names], lr=hp['opt_lr'] * 0.001,
                                                weight_decay=hp['weight_decay'])
         self.losses = torch.zeros(8, device=dev)
-        self.begin(target_rot_mat, mask, z_shallow, z_deep)
+        self.begin(target_rot_mat, mask, z_shallow, z_deep, root_trans=root_trans)
 
-    def begin(self, target_rot_mat, mask, z_shallow=None, z_deep=None):
+    def _init_trajectory(self, tm, dev, B, T, bp):
+        """Buffers and the frozen trajectory engine of the `optimize_trajectory` term (:1376-1389)."""
+        from .traj_engine import TrajEngine
+        from .trajectory_pred_model import JOINT_POS_SLICE, ROOT_V_SLICE
+        tm = getattr(tm, "model", tm)                 # a Trainer is accepted like the reference's `trajectory_trainer`
+        if tm is None:
+            raise ValueError("optimize_trajectory needs the trained TrajectoryModel (trajectory_model=...)")
+        if not tm.hp['trajectory_input_joint_pos']:
+            raise NotImplementedError("optimize_trajectory with a rotation-input TrajectoryModel")
+        teng = TrajEngine(dict(tm.hp, train_seq_len=T), dict(tm.named_parameters()),
+                          tm.std_vals[0, ROOT_V_SLICE[0]:ROOT_V_SLICE[1]].cpu().numpy(), dev,
+                          parents=tm.fk_layer.parent_list, input_grad=True)
+
+        def f(*shape):
+            return torch.zeros(*shape, device=dev)
+        self.traj = dict(eng=teng, w=teng.workspace(B),
+                         jm=tm.mean_vals[0, JOINT_POS_SLICE[0]:JOINT_POS_SLICE[1]].to(dev).contiguous(),
+                         js=tm.std_vals[0, JOINT_POS_SLICE[0]:JOINT_POS_SLICE[1]].to(dev).contiguous(),
+                         mean3=tm.mean_vals[0, ROOT_V_SLICE[0]:ROOT_V_SLICE[1]].to(dev).contiguous(),
+                         std3=tm.std_vals[0, ROOT_V_SLICE[0]:ROOT_V_SLICE[1]].to(dev).contiguous(),
+                         c6=f(B, T, 24, 6), R=f(B, T, 24, 3, 3), pos=f(B, T, 24, 3), xn=f(B, T, 72), dpos=f(B, T, 72),
+                         d6=f(B, T, 144), d6s=f(144 * T, bp), gt=f(3 * T, bp),
+                         part=f(ops.keyframe_root_loss_blocks(T, B, bp)), l=f(1), n=0)
+
+    def begin(self, target_rot_mat, mask, z_shallow=None, z_deep=None, root_trans=None):
         """Load a window batch (same shape as the refiner was built for) and start over: iteration 0, fresh Adam state,
         the anchor = the model's current decoder.  No buffer a captured graph addresses is replaced."""
         eng, w, hp = self.eng, self.w, self.hp
@@ -90,6 +122,20 @@ class LatentRefiner:
         r6 = torch.stack((R[..., 0], R[..., 1]), dim=-2).reshape(B, T, 144).contiguous()
         eng.stage_batch(w, r6, R.reshape(B, T, 216))
         ops.aos_to_soa(mask.to(device=dev, dtype=torch.float32).contiguous(), w["MK"], B, T, 24, bp)
+        if self.traj is not None:
+            if root_trans is None or tuple(root_trans.shape) != (B, T, 3):
+                raise ValueError("optimize_trajectory needs root_trans of shape (%d, %d, 3)" % (B, T))
+            tj = self.traj
+            ops.aos_to_soa(root_trans.to(device=dev, dtype=torch.float32).contiguous(), tj["gt"], B, T, 3, bp)
+            # N of the mean (:1043): three components per pair of consecutive selected indices, all windows together; as
+            # released the selection is row 0 of each window's (T, 24) mask, i.e. the joints observed in frame 0 (< T)
+            sel = (mask[:, 0, :min(24, T)] != 0).sum(dim=1)
+            n = 3 * int(torch.clamp(sel - 1, min=0).sum())
+            if tj["n"] not in (0, n) and self._graphs:
+                raise ValueError("the captured iteration bakes in the number of key-frame pairs (%d), this batch has %d"
+                                 % (tj["n"] // 3, n // 3))
+            tj["n"] = n
+            tj["eng"].pack_weights()                  # frozen: once per window batch
         with torch.no_grad():
             if z_shallow is None:                     # :1317-1318: the deep code first, then the shallow one
                 z_deep = torch.randn(self.z_deep.shape, device=dev)
@@ -154,6 +200,8 @@ class LatentRefiner:
         n6, nR, nP = B * T * 144, B * T * 216, B * T * 72
         ops.decode_tail_loss(w["D%d" % (L - 1)], w["X0"], w["GR"], w["GP"], eng.offsets, T, B, bp, hp["rec_6d_w"] / n6,
                              hp["rec_rot_w"] / nR, hp["rec_pose_w"] / nP, w["dD%d" % (L - 1)], w["MSEP"], mask=w["MK"])
+        if self.traj is not None and self.traj["n"] > 0:
+            self._trajectory_term(w, L, B, T, bp)
         _, _, dconv = eng.names()
         eng._skip_wgrad = not decoder_phase
         try:
@@ -186,7 +234,35 @@ class LatentRefiner:
         # total = w6 l6 + wR lR + wP lP + reg_w * l_reg + reg_w_decoder * l_reg_decoder  (:1388-1389)
         ops.vae_loss_finalize(w["MSEP"], w["REGP"], dregp, 1.0 / n6, 1.0 / nR, 1.0 / nP, 1.0, 1.0, hp["rec_6d_w"],
                               hp["rec_rot_w"], hp["rec_pose_w"], reg_dec, reg_w, self.losses)
+        if self.traj is not None and self.traj["n"] > 0:          # + reg_w_trajectory * l_rec_trajectory (:1388-1389)
+            self.losses[7:8].copy_(self.traj["l"])
+            self.losses[0:1].add_(self.traj["l"], alpha=float(hp.get("reg_w_trajectory", 0.0)))
         return self.losses
+
+    def _trajectory_term(self, w, L, B, T, bp):
+        """l_rec_trajectory (:1376-1389) and its gradient, ADDED to dL/d(decoder output) before the decoder's backward."""
+        eng, hp, tj = self.eng, self.hp, self.traj
+        teng, tw = tj["eng"], tj["w"]
+        dec = w["D%d" % (L - 1)]
+        # sampled_seq_test (trajectory_pred_model.py:397-439): FK of the decoded rotations, standardised, through the encoder
+        ops.decode_tail_fwd(dec, eng.offsets, T, B, bp, tj["c6"], tj["R"], tj["pos"])
+        torch.sub(tj["pos"].view(B, T, 72), tj["jm"], out=tj["xn"])
+        tj["xn"].div_(tj["js"])
+        teng.encode(tw, tj["xn"])
+        w_t = float(hp.get("reg_w_trajectory", 0.0))
+        nb = ops.keyframe_root_loss(tw["V"], tj["gt"], w["MK"], tj["mean3"], tj["std3"], T, B, bp, 2.0 * w_t / tj["n"],
+                                    tw["dV"], tj["part"])
+        ops.finalize_sum(tj["part"], nb, 1, 0, 1.0 / tj["n"], tj["l"])
+        if w_t == 0.0:
+            return
+        # back: trajectory encoder (data gradients only) -> de-standardise -> FK / lift backward -> + dL/d(decoder output)
+        teng.backward_input(tw, bp)
+        ops.soa_to_aos(tw["dX0"], tj["dpos"], B, T, 72, bp)
+        tj["dpos"].div_(tj["js"])
+        ops.fk_bwd(tj["c6"].view(B * T, 24, 6), 6, eng.offsets, 0, eng.parents, B * T, None, tj["dpos"].view(B * T, 24, 3),
+                   tj["d6"].view(B * T, 24, 6))
+        ops.aos_to_soa(tj["d6"], tj["d6s"], B, T, 144, bp)
+        w["dD%d" % (L - 1)].add_(tj["d6s"])
 
     def _graph_for(self, decoder_phase, opt):
         g = self._graphs.get(decoder_phase)

@@ -270,10 +270,12 @@ class TwoHierSAVAEModel(nn.Module):
         loss = (pred - gt) ** 2 * m
         return loss.mean(), loss.reshape(loss.shape[0], loss.shape[1], -1).mean(dim=-1)
 
-    def refine_window(self, target_rot_mat, mask, hp=None, z_shallow=None, z_deep=None, iterations=None):
+    def refine_window(self, target_rot_mat, mask, hp=None, z_shallow=None, z_deep=None, iterations=None,
+                      trajectory_trainer=None, root_trans=None):
         """The test-time optimisation loop of the interpolation / completion routines (seq_two_hier_sa_vae.py:1356-1429) for
         a batch of windows: target_rot_mat (B,T,24,3,3), mask (B,T,24).  Returns (cont6d, R, pos, loss history (it, 8));
-        the decoder is restored afterwards, as the reference optimises a deep copy."""
+        the decoder is restored afterwards, as the reference optimises a deep copy.  With hp['optimize_trajectory']:
+        trajectory_trainer (the trained TrajectoryModel or its Trainer, :1378) and root_trans (B,T,3), :1381."""
         from .refine import LatentRefiner
         hp = self.hp if hp is None else hp
         # one refiner (buffers, optimisers, two captured graphs) per window shape and set of hyper-parameters, reused
@@ -283,9 +285,10 @@ class TwoHierSAVAEModel(nn.Module):
         cache = self.__dict__.setdefault("_refiners", {})
         ref = cache.get(key)
         if ref is None or ref.eng is not self.engine():
-            ref = cache[key] = LatentRefiner(self, hp, target_rot_mat, mask, z_shallow, z_deep)
+            ref = cache[key] = LatentRefiner(self, hp, target_rot_mat, mask, z_shallow, z_deep,
+                                             trajectory_model=trajectory_trainer, root_trans=root_trans)
         else:
-            ref.begin(target_rot_mat, mask, z_shallow, z_deep)
+            ref.begin(target_rot_mat, mask, z_shallow, z_deep, root_trans=root_trans)
         try:
             hist = ref.run(iterations)
             c6, R, pos = ref.decode()

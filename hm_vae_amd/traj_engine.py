@@ -49,9 +49,12 @@ class TrajPlan:
 class TrajEngine(_StepBase):
     """Owns device tables + workspaces; borrows the parameter tensors (dict reference-name -> Parameter)."""
 
-    def __init__(self, hp, params, std_root, device, parents=topology.SMPL24_PARENTS):
+    def __init__(self, hp, params, std_root, device, parents=topology.SMPL24_PARENTS, input_grad=False):
+        """input_grad: also build the first convolution's backward-data side (the test-time optimisation loop's trajectory
+        term differentiates the frozen model with respect to its INPUT, seq_two_hier_sa_vae.py:1376-1389)."""
         _lib.load()
         self._init_step_base(device)
+        self.input_grad = bool(input_grad)
         self.hp = hp
         self.p = p = TrajPlan(hp, parents)
         self.params = params
@@ -60,7 +63,7 @@ class TrajEngine(_StepBase):
         T = p.T
         for i in range(p.L):
             self.conv.append(ops.conv_gemm(device, p.neigh[i], p.enc_cin[i], p.enc_cout[i], p.K, 1, p.pad, p.pad_mode, T,
-                                           need_dx=(i > 0)))
+                                           need_dx=(i > 0 or input_grad)))
             self.pool.append(ops.PoolOp(device, p.pooling[i], p.edge_num[i], p.enc_cout[i] // p.edge_num[i]))
         # fc_mapping over the frames: one "edge" that owns every latent channel, one tap, T positions
         self.head = ops.conv_gemm(device, [[0]], p.latent_ch, 3, 1, 1, 0, p.pad_mode, T, need_dx=True)
@@ -87,6 +90,8 @@ class TrajEngine(_StepBase):
             pc = p.ch_base[i + 1] * p.edge_num[i + 1]
             w["A%d" % i], w["dA%d" % i] = buf(pc * T), buf(pc * T)
         w["V"], w["dV"] = buf(3 * T), buf(3 * T)
+        if self.input_grad:
+            w["dX0"] = buf(p.enc_cin[0] * T)
         nb = ops.traj_loss_blocks(T, B, bp)
         w["LP"] = torch.zeros(nb, 2, device=dev)
         w["losses"] = torch.zeros(9, device=dev)
@@ -196,6 +201,16 @@ class TrajEngine(_StepBase):
             self._backward(w, bp)
             self.assign_grads()
         return w["losses"]
+
+    def backward_input(self, w, bp):
+        """dL/d(input) from w["dV"]: the data-gradient chain alone, down to w["dX0"] (no weight gradients: the model is frozen)."""
+        if not self.input_grad:
+            raise _lib.HmvaeError("this engine was built without the first layer's backward-data side (input_grad=True)")
+        p, T, L = self.p, self.p.T, self.p.L
+        self.head.backward_data(w["dV"], w["dA%d" % (L - 1)], bp)
+        for i in range(L - 1, -1, -1):
+            self.pool[i].backward(w["dA%d" % i], w["A%d" % i], w["dY%d" % i], T, bp)
+            self.conv[i].backward_data(w["dY%d" % i], w["dA%d" % (i - 1)] if i > 0 else w["dX0"], bp)
 
     def _backward(self, w, bp):
         p, T = self.p, self.p.T

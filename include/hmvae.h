@@ -470,6 +470,19 @@ int hmvae_traj_loss(const float* v, const float* g, const float* std3, int32_t T
 int hmvae_traj_loss_finalize(const float* partial, int32_t n_blocks, float inv_n, float w_v, float w_t, float* out9,
                              hmvae_stream_t stream);
 
+/* The trajectory term of the test-time optimisation loop (seq_two_hier_sa_vae.py:1376-1389 with cal_key_frame_root_loss
+ * :1031-1045 and gen_motion_w_trajectory :486-499).  v: SoA (3*T rows x bp) normalised root velocity the trajectory model
+ * predicts for the decoded window; gt: SoA (3*T x bp) ground-truth root translation; mask: SoA (24*T x bp) of
+ * l2_masked_criterion (row j*T + t) -- as released, the selected "key frames" are the indices j whose mask entry at FRAME 0
+ * is non-zero; mean3 / std3: mean_vals / std_vals[576:579] (device).  For consecutive selected j' < j the loss term is
+ * e^2 with e = sum_{s=j'+1..j} (mean + std*v[s]) - (gt[j] - gt[j']), and dv[s] = grad_scale * std * e for the s of that
+ * interval (0 elsewhere): with grad_scale = 2*reg_w_trajectory/N, N = 3 * sum over windows of (selected - 1) counted by the
+ * caller, dv is the gradient of reg_w_trajectory * mean(e^2).  partial: [n_blocks] block sums of e^2.  All-NULL buffers:
+ * only *n_blocks_out is set. */
+int hmvae_keyframe_root_loss(const float* v, const float* gt, const float* mask, const float* mean3, const float* std3,
+                             int32_t T, int32_t B, int32_t bp, float grad_scale, float* dv, float* partial,
+                             int32_t* n_blocks_out, hmvae_stream_t stream);
+
 /* out[0..n_out) : fixed-order sums of partial[i*stride + k], scaled */
 int hmvae_finalize_sums(const float* partial, int32_t n_partial, int32_t stride, int32_t k, float scale, float* out,
                         hmvae_stream_t stream);

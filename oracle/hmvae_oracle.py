@@ -478,13 +478,19 @@ class OracleVAE:
 
 
     # -- test-time optimisation (seq_two_hier_sa_vae.py:1356-1389; masked criterion :717-735) -- SURVEY.md §8 row f-2
-    def refine_forward(self, z_shallow, z_deep, target_rmat, mask, anchor=None, backward=True):
+    def refine_forward(self, z_shallow, z_deep, target_rmat, mask, anchor=None, backward=True, traj=None,
+                       root_trans=None, joint_mean=None, joint_std=None):
         """One iteration's losses of the interpolation / completion loop and their gradients.
 
         z_shallow (B,k1,d0), z_deep (B,kL,d): leaf tensors (requires_grad) or plain tensors; target_rmat (B,T,24,3,3);
         mask (B,T,24); anchor: name -> original decoder tensor (the `optimize_decoder` regulariser :1369-1373) or None.
         The released routine does not run (stale `_decode` signature), so nothing pins this restatement but the
         reference's text: parity unpinned.
+        traj (an OracleTrajectory with the trained trajectory model's weights), root_trans (B,T,3), joint_mean / joint_std
+        (72,) = mean_vals / std_vals[360:432]: the `optimize_trajectory` term (:1376-1389) -- sampled_seq_test
+        (trajectory_pred_model.py:397-439) on the decoded rotations, then cal_key_frame_root_loss (:1031-1045) restated AS
+        RELEASED: the caller passes the (T, 24) mask and the routine selects with `nonzero(mask[0])`, i.e. the JOINTS
+        observed in frame 0 serve as frame indices; a batch of windows averages over all windows' terms.
         """
         hp, p = self.hp, self.plan
         b, T = target_rmat.shape[0], target_rmat.shape[1]
@@ -509,11 +515,29 @@ class OracleVAE:
         reg_dec_w = hp.get("reg_w_decoder", 0.0) if anchor is not None else 0.0
         total = hp["rec_6d_w"] * l6 + hp["rec_rot_w"] * lr + hp["rec_pose_w"] * lp + hp.get("reg_w", 0.0) * l_reg + \
             reg_dec_w * l_reg_dec
+        l_traj = torch.zeros(())
+        if traj is not None:
+            jm = torch.as_tensor(joint_mean, dtype=self.dtype).reshape(1, 72)
+            js = torch.as_tensor(joint_std, dtype=self.dtype).reshape(1, 72)
+            x = ((pos.reshape(-1, 72) - jm) / js).reshape(b, T, 72)                          # standardize_data_specify_dim
+            v = traj.root_velocity(x)                                                         # (B,T,3) normalised
+            pred = traj.trajectory(pos.to(traj.dtype).transpose(0, 1), v.transpose(0, 1))    # (T,B,24,3), :486-499
+            pred_root = pred[:, :, 0, :]                                                      # :1379
+            terms = []
+            for i in range(b):
+                idx = torch.nonzero(mask[i][0]).squeeze(-1)                                   # :1036, row 0 of the (T,24) mask
+                sp, sg = pred_root[:, i][idx], root_trans[i].to(self.dtype)[idx]
+                terms.append(((sp[1:] - sp[:-1]) - (sg[1:] - sg[:-1])) ** 2)
+            terms = torch.cat(terms).reshape(-1)
+            if terms.numel():
+                l_traj = terms.mean()
+            total = total + hp.get("reg_w_trajectory", 0.0) * l_traj
         if backward:
             for t in list(self.params.values()) + [z_shallow, z_deep]:
                 t.grad = None
             total.backward()
-        return dict(total=total, rec_6d=l6, rec_rot=lr, rec_pose=lp, reg=l_reg, reg_decoder=l_reg_dec, c6=c6, R=R, pos=pos)
+        return dict(total=total, rec_6d=l6, rec_rot=lr, rec_pose=lp, reg=l_reg, reg_decoder=l_reg_dec, trajectory=l_traj,
+                    c6=c6, R=R, pos=pos)
 
 
 # --------------------------------------------------------------------------------------

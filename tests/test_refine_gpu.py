@@ -156,6 +156,106 @@ def test_one_iteration_matches_oracle(dev, decoder_phase):
     ref.restore()
 
 
+def test_keyframe_root_loss_kernel(dev):
+    """hmvae_keyframe_root_loss against float64 autograd of cal_key_frame_root_loss as released (:1031-1045): ragged batch,
+    windows with different selections (one with a single selected index: no term), padding columns poisoned."""
+    from hm_vae_amd import ops
+    T, B = 40, 70
+    bp = ops.pad_batch(B)
+    g = torch.Generator().manual_seed(7)
+    v = torch.randn(B, T, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    gt = torch.randn(B, T, 3, generator=g, dtype=torch.float64)
+    mean = torch.tensor([0.01, -0.02, 0.005], dtype=torch.float64)
+    std = torch.tensor([0.7, 1.3, 0.05], dtype=torch.float64)
+    mask = (torch.rand(B, T, 24, generator=g) < 0.6).float()
+    mask[0, 0, :] = 0
+    mask[0, 0, 5] = 1                                # one selected index only
+    mask[1, 0, :] = 1
+    acc = torch.cumsum(torch.cat((torch.zeros(B, 1, 3, dtype=torch.float64), (mean + std * v)[:, 1:]), dim=1), dim=1)
+    terms = []
+    for b in range(B):
+        idx = torch.nonzero(mask[b][0]).squeeze(-1)
+        sp, sg = acc[b][idx], gt[b][idx]
+        terms.append((((sp[1:] - sp[:-1]) - (sg[1:] - sg[:-1])) ** 2).reshape(-1))
+    terms = torch.cat(terms)
+    n = terms.numel()
+    w_t = 0.37
+    (w_t * terms.mean()).backward()
+    vs, gs = torch.zeros(3 * T, bp, device=dev), torch.zeros(3 * T, bp, device=dev)
+    mk = torch.zeros(24 * T, bp, device=dev)
+    ops.aos_to_soa(v.detach().float().to(dev).contiguous(), vs, B, T, 3, bp)
+    ops.aos_to_soa(gt.float().to(dev).contiguous(), gs, B, T, 3, bp)
+    ops.aos_to_soa(mask.to(dev).contiguous(), mk, B, T, 24, bp)
+    vs[:, B:] = 7.0
+    mk[:, B:] = 1.0
+    dv = torch.full((3 * T, bp), 9.0, device=dev)
+    part = torch.zeros(ops.keyframe_root_loss_blocks(T, B, bp), device=dev)
+    nb = ops.keyframe_root_loss(vs, gs, mk, mean.float().to(dev), std.float().to(dev), T, B, bp, 2 * w_t / n, dv, part)
+    out = torch.zeros(1, device=dev)
+    ops.finalize_sum(part, nb, 1, 0, 1.0 / n, out)
+    assert abs(float(out) - float(terms.mean())) < 1e-5 * float(terms.mean())
+    got = torch.empty(B, T, 3, device=dev)
+    ops.soa_to_aos(dv, got, B, T, 3, bp)
+    assert rel_err(got.cpu().numpy(), v.grad.numpy()) < 1e-5
+    assert float(dv[:, B:].abs().max()) == 0.0
+
+
+def test_trajectory_term_matches_oracle(dev):
+    """optimize_trajectory (:1376-1389): one iteration's losses and latent gradients with the trajectory term against the
+    oracle (frozen trajectory model of the shipped trajectory config at the window length, name-seeded weights)."""
+    from hm_vae_amd.refine import LatentRefiner
+    from hm_vae_amd.trainer_motion_vae import Trainer
+    from helpers import load_traj_cfg
+    cfg = interp_cfg()
+    cfg.update(reg_w=0.05, optimize_trajectory=True, reg_w_trajectory=3.0)
+    model, plan, seeded = make_model(cfg, dev)
+    B, T = 3, cfg["train_seq_len"]
+    tcfg = load_traj_cfg(T)
+    ttr = Trainer(tcfg)
+    tplan = O.TrajPlan(tcfg)
+    tseed = O.traj_name_seeded_params(tplan)
+    sd = ttr.model.state_dict()
+    for k, v in tseed.items():
+        sd[k] = v.clone()
+    ttr.model.load_state_dict(sd)
+    ttr.cuda()
+    tm = ttr.model
+    target, mask = smooth_rotations(B, T, 21), joint_mask(B, T, cfg["interpolation_window"], 22)
+    g = torch.Generator().manual_seed(29)
+    z0 = torch.randn(B, plan.edge_num[1], plan.lat_dim[0], generator=g)
+    zd = torch.randn(B, plan.edge_num[plan.L], plan.lat_dim[plan.L - 1], generator=g)
+    root = torch.cumsum(0.02 * torch.randn(B, T, 3, generator=g), dim=1)
+    ref = LatentRefiner(model, cfg, target, mask, z0, zd, trajectory_model=ttr, root_trans=root)
+    ls = ref.loss_and_grads(False).cpu().numpy()
+
+    orc = O.OracleVAE(cfg, seeded, offsets=offsets())
+    mean, std = tm.mean_vals[0].cpu(), tm.std_vals[0].cpu()
+    otr = O.OracleTrajectory(tcfg, tseed, mean[576:579].numpy(), std[576:579].numpy())
+    z0o, zdo = z0.clone().requires_grad_(True), zd.clone().requires_grad_(True)
+    o = orc.refine_forward(z0o, zdo, target, mask, traj=otr, root_trans=root, joint_mean=mean[360:432], joint_std=std[360:432])
+    assert float(o["trajectory"]) > 0
+    want = np.array([float(o[k]) for k in ("total", "rec_6d", "rec_rot", "rec_pose", "reg", "trajectory")])
+    got = np.array([ls[0], ls[2], ls[3], ls[4], ls[5], ls[7]])
+    assert rel_err(got, want) < TOL, (got, want)
+    assert rel_err(ref.z_shallow.grad.cpu().numpy(), z0o.grad.numpy()) < TOL
+    assert rel_err(ref.z_deep.grad.cpu().numpy(), zdo.grad.numpy()) < TOL
+    # the term is what moved the gradient: without it the latents' gradient differs
+    cfg2 = dict(cfg, optimize_trajectory=False)
+    ref2 = LatentRefiner(model, cfg2, target, mask, z0, zd)
+    ref2.loss_and_grads(False)
+    assert rel_err(ref2.z_deep.grad.cpu().numpy(), zdo.grad.numpy()) > 10 * TOL
+    with pytest.raises(ValueError):
+        LatentRefiner(model, cfg, target, mask, z0, zd)                   # the term needs the trajectory model
+    # the loop with the term: hipGraph replay (second iteration captured, then replayed) == eager launches
+    hists = []
+    for use_graph in (False, True):
+        r = LatentRefiner(model, cfg, target, mask, z0, zd, use_graph=use_graph, trajectory_model=ttr, root_trans=root)
+        hists.append(r.run(5))
+        r.restore()
+    assert rel_err(hists[1], hists[0]) < 2e-6
+    assert (hists[0][:, 7] > 0).all() and hists[0][-1, 0] < hists[0][0, 0]
+
+
 def test_short_loop_matches_oracle_adam(dev, monkeypatch):
     """3 latent iterations then 3 decoder iterations (the phase switch pulled in from 50) against torch.optim.Adam on the
     oracle: same loss history."""
