@@ -1108,6 +1108,138 @@ __global__ __launch_bounds__(256) void decode_tail_loss_kernel(const float* __re
     }
 }
 
+// ---- the same tail in three phases over an LDS tile (round 2): the serial part is 3x3 algebra only ----
+// decode_tail_loss_kernel above walks each subtree joint by joint and does EVERYTHING of a joint inside the walk: six row
+// loads, the lift, 18 target loads, the losses, later the lift's backward -- a dependent chain per wave with one wave per SIMD
+// (348 registers), 36-40 us on the training step's critical path and 0.17 of the HBM rate at 262 144 frames.  Here, as in
+// fk_bwd_aos_kernel: (A) every thread lifts six joints of its frame in parallel and books the 6D / matrix errors (their sums,
+// the direct dL/dR into the tile, the direct dL/d6D kept in registers); (B) the chain by subtree (fk_bwd_by_role) reads lifted
+// rotations from the tile, adds the position loss and leaves every joint's TOTAL dL/dR in the tile; (C) the lift's backward
+// for the same six joints in parallel, plus the direct 6D term, straight to global memory.  All global accesses are 256-byte
+// row segments (lanes = consecutive batch columns).
+template <bool MK>
+struct TailChain {
+    const float* R;        // LDS row of this frame: lifted rotations, J*9
+    float* dR;             // LDS row J*9: direct dL/dR in, total dL/dR out
+    const float* gP;       // gt positions + t*bp + b
+    const float* mk;       // mask + t*bp + b (MK only)
+    const float* offs;
+    size_t rs;
+    float sP, cP;
+    __device__ __forceinline__ void rot(int j, M3& Rm) const {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rm.a[k] = R[j * 9 + k];
+    }
+    __device__ __forceinline__ V3 off(int j) const { return {offs[j * 3], offs[j * 3 + 1], offs[j * 3 + 2]}; }
+    __device__ __forceinline__ V3 grad_P(int j, V3 P) {
+        const float ex = P.x - gP[(size_t)(j * 3) * rs], ey = P.y - gP[(size_t)(j * 3 + 1) * rs],
+                    ez = P.z - gP[(size_t)(j * 3 + 2) * rs];
+        if constexpr (MK) {
+            const float w = mk[(size_t)j * rs], c = cP * w;
+            sP += w * (ex * ex + ey * ey + ez * ez);
+            return {c * ex, c * ey, c * ez};
+        }
+        sP += ex * ex + ey * ey + ez * ez;
+        return {cP * ex, cP * ey, cP * ez};
+    }
+    __device__ __forceinline__ void grad_R(int j, const M3&, M3& g) const {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) g.a[k] = dR[j * 9 + k];
+    }
+    __device__ __forceinline__ void emit(int j, const M3& g) const {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dR[j * 9 + k] = g.a[k];
+    }
+};
+
+constexpr int TL3_LR = NJ * 9 + 1;                   // odd row length: conflict-free per-frame accesses
+constexpr int TL3_JT = NJ * TL_FRAMES / 256;         // joints per thread in the parallel phases (6)
+template <bool MK>
+__global__ __launch_bounds__(256) void decode_tail_loss3_kernel(const float* __restrict__ dec, const float* __restrict__ g6,
+                                                                const float* __restrict__ gR, const float* __restrict__ gP,
+                                                                const float* __restrict__ mask,
+                                                                const float* __restrict__ offs, int T, int B, int bp,
+                                                                float c6, float cR, float cP, float* __restrict__ ddec,
+                                                                float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float tl3[];
+    float* sR = tl3;                                             // [TL_FRAMES][TL3_LR] lifted rotations
+    float* sD = sR + TL_FRAMES * TL3_LR;                         // [TL_FRAMES][TL3_LR] dL/dR
+    float (*xch)[12][TL_FRAMES] = (float (*)[12][TL_FRAMES])(sD + TL_FRAMES * TL3_LR);
+    float (*psum)[3] = (float (*)[3])(&xch[4][0][0]);
+    const int f = threadIdx.x & 63;
+    const int jg = threadIdx.x >> 6;                  // wave-uniform: joints jg, jg + 4, ... in the parallel phases, the role in B
+    const int b = blockIdx.x * TL_FRAMES + f;
+    const int t = blockIdx.y;
+    const size_t rs = (size_t)T * bp;
+    const size_t o = (size_t)t * bp + b;
+    const bool live = b < B;
+    float in[TL3_JT][6], d6[TL3_JT][6];
+    float s6 = 0.f, sRs = 0.f;
+    // ---- A ----
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < TL3_JT; ++i) {
+            const int j = jg + 4 * i;
+            const float w = MK ? mask[o + (size_t)j * rs] : 1.f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) in[i][k] = dec[o + (size_t)(j * 6 + k) * rs];
+            M3 Rm;
+            lift6d(in[i], Rm);
+            float a6 = 0.f, aR = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float e = in[i][k] - g6[o + (size_t)(j * 6 + k) * rs];
+                a6 += e * e;
+                d6[i][k] = (MK ? c6 * w : c6) * e;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float e = Rm.a[k] - gR[o + (size_t)(j * 9 + k) * rs];
+                aR += e * e;
+                sR[f * TL3_LR + j * 9 + k] = Rm.a[k];
+                sD[f * TL3_LR + j * 9 + k] = (MK ? cR * w : cR) * e;
+            }
+            s6 += MK ? w * a6 : a6;
+            sRs += MK ? w * aR : aR;
+        }
+    }
+    __syncthreads();
+    // ---- B ----
+    TailChain<MK> io{sR + f * TL3_LR, sD + f * TL3_LR, gP + o, MK ? mask + o : nullptr, offs, rs, 0.f, cP};
+    fk_bwd_by_role<TL_FRAMES>(jg, f, live, io, xch);
+    __syncthreads();
+    // ---- C ----
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < TL3_JT; ++i) {
+            const int j = jg + 4 * i;
+            M3 g;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) g.a[k] = sD[f * TL3_LR + j * 9 + k];
+            float din[6];
+            lift6d_bwd(in[i], g, din);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ddec[o + (size_t)(j * 6 + k) * rs] = din[k] + d6[i][k];
+        }
+    } else if (b < bp) {
+#pragma unroll
+        for (int i = 0; i < TL3_JT; ++i)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ddec[o + (size_t)((jg + 4 * i) * 6 + k) * rs] = 0.f;   // padded columns: zero gradient
+    }
+    const float w6 = wave_sum_f(s6), wR = wave_sum_f(sRs), wP = wave_sum_f(live ? io.sP : 0.f);
+    if (f == 0) {
+        psum[jg][0] = w6;
+        psum[jg][1] = wR;
+        psum[jg][2] = wP;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float* p = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3;
+        p[threadIdx.x] = (psum[0][threadIdx.x] + psum[1][threadIdx.x]) + (psum[2][threadIdx.x] + psum[3][threadIdx.x]);
+    }
+}
+
 struct TailFwd {
     const float* x;
     const float* offs;
@@ -1275,6 +1407,27 @@ static int tail_loss_launch(const float* dec_out, const float* gt6d, const float
     if (n_blocks_out) *n_blocks_out = (int32_t)(grid.x * grid.y);
     if (!dec_out && !gt6d && !gtR && !gtP && !mask && !d_dec_out && !partial) return HMVAE_OK;      // size query
     if (!dec_out || !gt6d || !gtR || !gtP || !offsets || !d_dec_out || !partial || (masked && !mask)) return HMVAE_ERR_ARG;
+    static int three_phase = -1;
+    if (three_phase < 0) {
+        const char* e = getenv("HMVAE_TAIL3");       // "0": the joint-by-joint walk (round 1), kept for the A/B
+        three_phase = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (three_phase) {
+        const size_t lds = sizeof(float) * (2 * TL_FRAMES * TL3_LR + 4 * 12 * TL_FRAMES + 16);
+        static bool attr[2] = {false, false};
+        const void* fn = masked ? (const void*)decode_tail_loss3_kernel<true> : (const void*)decode_tail_loss3_kernel<false>;
+        if (!attr[masked]) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return HMVAE_ERR_LAUNCH;
+            attr[masked] = true;
+        }
+        if (masked)
+            hipLaunchKernelGGL(decode_tail_loss3_kernel<true>, grid, block, lds, (hipStream_t)stream, dec_out, gt6d, gtR, gtP, mask,
+                               offsets, T, B, bp, 2.f * scale_6d, 2.f * scale_rot, 2.f * scale_pos, d_dec_out, partial);
+        else
+            hipLaunchKernelGGL(decode_tail_loss3_kernel<false>, grid, block, lds, (hipStream_t)stream, dec_out, gt6d, gtR, gtP, mask,
+                               offsets, T, B, bp, 2.f * scale_6d, 2.f * scale_rot, 2.f * scale_pos, d_dec_out, partial);
+        return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
+    }
     if (masked)
         hipLaunchKernelGGL(decode_tail_loss_kernel<true>, grid, block, 0, (hipStream_t)stream, dec_out, gt6d, gtR, gtP, mask,
                            offsets, T, B, bp, 2.f * scale_6d, 2.f * scale_rot, 2.f * scale_pos, d_dec_out, partial);
