@@ -25,6 +25,7 @@ EARLY_SIDE = _os0.environ.get("HMVAE_EARLY_SIDE", "1") != "0"
 PACK_SPLIT = _os0.environ.get("HMVAE_PACK_SPLIT", "1") != "0"
 # the decoder's / transposed layouts are packed on the early stream BEFORE the targets and the noise are staged there
 LATE_PACK_FIRST = _os0.environ.get("HMVAE_LATE_PACK_FIRST", "1") != "0"
+SHALLOW_SIDE = _os0.environ.get("HMVAE_SHALLOW_SIDE", "1") != "0"
 
 
 class VaePlan:
@@ -254,6 +255,7 @@ class VaeEngine(_StepBase):
         # Decoder.forward's API; they are built lazily
         self._init_step_base(device)
         self._ws = {}
+        self._shallow = None
         self._multipack = None
         self._multipack_late = None
         self._multipack_dec = None
@@ -475,11 +477,14 @@ class VaeEngine(_StepBase):
         ops.fk_fwd(rmat, 9, self.offsets, 0, self.parents, B * T, None, w["pos_aos"])
         ops.aos_to_soa(w["pos_aos"], w["GP"], B, T, 72, bp)
 
-    def encode(self, w, heads):
+    def encode(self, w, heads, after_first=None):
+        """after_first: called once layer 0 has been launched (the training step starts the shallow latent branch there)."""
         p, P, bp = self.p, self.params, w["bp"]
         enc_w, enc_b, _ = self.names()
         x = w["X0"]
         for i in range(p.L):
+            if i == 1 and after_first is not None:
+                after_first()
             if i == 1 and self._mid_event is not None:           # layouts of layers 1.. were packed beside layer 0
                 torch.cuda.current_stream().wait_event(self._mid_event)
                 self._mid_event = None
@@ -492,14 +497,19 @@ class VaeEngine(_StepBase):
         for i in heads:
             self.enc_lin[i].forward(w["A%d" % i], w["ZD%d" % i], bp, bias=P["enc.latent_enc_layers.%d.bias" % i])
 
-    def decode_feats(self, w):
-        """Decoder.forward (seq_two_hier_sa_vae.py:260-294) from Z{L-1} and Z0; result in D{L-1}."""
+    def decode_feats(self, w, shallow_done=None):
+        """Decoder.forward (seq_two_hier_sa_vae.py:260-294) from Z{L-1} and Z0; result in D{L-1}.
+        shallow_done: an event after which the shallow head's part of the concat buffer is in place (the training step
+        computes it on a side stream, see train_step); the last layer waits for it."""
         p, P, bp, L = self.p, self.params, w["bp"], self.p.L
         _, _, dconv = self.names()
         self.dec_lin[0].forward(w["Z%d" % (L - 1)], w["H0"], bp, bias=P["dec.latent_dec_layers.0.bias"])
-        self.dec_lin[L - 1].forward(w["Z0"], w["D%d" % (L - 2)], bp, bias=P["dec.latent_dec_layers.%d.bias" % (L - 1)])
+        if shallow_done is None:
+            self.dec_lin[L - 1].forward(w["Z0"], w["D%d" % (L - 2)], bp, bias=P["dec.latent_dec_layers.%d.bias" % (L - 1)])
         src = w["H0"]
         for i in range(L):
+            if i == L - 1 and shallow_done is not None:
+                torch.cuda.current_stream().wait_event(shallow_done)
             bias = P[dconv[i] + ".bias"] if p.dec_bias[i] else None
             if self.dec_conv[i].fused_front:
                 x = src
@@ -573,13 +583,48 @@ class VaeEngine(_StepBase):
                 eps.append(e)
             if self._late_packs:
                 self._multipack_late.run(self._late_packs)
-        self.encode(w, (0, L - 1))
+            eps_ready = None
+            if early is not None and SHALLOW_SIDE:
+                eps_ready = self._event("eps_ready")
+                eps_ready.record(early)
+        shallow_done = None
+        if eps_ready is not None:
+            # The shallow latent branch (level-0 head -> reparametrisation -> its decoder head into the last layer's concat
+            # buffer) only needs the first encoder layer's output: it runs on a stream of its own beside the encoder instead
+            # of as three launches between the encoder's last and the decoder's first convolution (1.510 -> 1.497 ms,
+            # interleaved A/B; the same move for the branch's BACKWARD -- its two data-gradient launches beside the decoder's
+            # backward instead of between decoder and encoder -- gave the gain back, 1.509 ms, and is not done).
+            mid_event = self._mid_event
+
+            def shallow():
+                main = torch.cuda.current_stream()
+                if self._shallow is None:
+                    self._shallow = torch.cuda.Stream(device=self.device)
+                sb = self._shallow
+                self._stream_wait(sb, main, "shallow_fork")
+                if mid_event is not None:
+                    sb.wait_event(mid_event)               # the head's layout is packed with layers 1..
+                sb.wait_event(eps_ready)                   # noise + the decoder heads' layouts (early stream)
+                with torch.cuda.stream(sb):
+                    k, d = p.edge_num[1], p.lat_dim[0]
+                    self.enc_lin[0].forward(w["A0"], w["ZD0"], bp, bias=P["enc.latent_enc_layers.0.bias"])
+                    ops.reparam_kl_fwd(w["ZD0"], eps[0], w["Z0"], w["KLP0"], k, d, B, bp, sample)
+                    self.dec_lin[L - 1].forward(w["Z0"], w["D%d" % (L - 2)], bp,
+                                                bias=P["dec.latent_dec_layers.%d.bias" % (L - 1)])
+                    ev = self._event("shallow_done")
+                    ev.record(sb)
+                return ev
+            holder = []
+            self.encode(w, (L - 1,), after_first=lambda: holder.append(shallow()))
+            shallow_done = holder[0]
+        else:
+            self.encode(w, (0, L - 1))
         if early is not None:
             self._stream_wait(torch.cuda.current_stream(), early, "early_join")
-        for i in (0, L - 1):
+        for i in ((L - 1,) if shallow_done is not None else (0, L - 1)):
             k, d = p.edge_num[i + 1], p.lat_dim[i]
             ops.reparam_kl_fwd(w["ZD%d" % i], eps[i], w["Z%d" % i], w["KLP%d" % i], k, d, B, bp, sample)
-        self.decode_feats(w)
+        self.decode_feats(w, shallow_done)
         n6, nR, nP = B * T * 144, B * T * 216, B * T * 72
         ops.decode_tail_loss(w["D%d" % (L - 1)], w["X0"], w["GR"], w["GP"], self.offsets, T, B, bp,
                              hp["rec_6d_w"] / n6, hp["rec_rot_w"] / nR, hp["rec_pose_w"] / nP, w["dD%d" % (L - 1)], w["MSEP"])
