@@ -33,7 +33,8 @@ class Gemm2Desc(C.Structure):
                 ("g_woff", _ptr), ("g_choff", _ptr), ("chan_rows", _ptr), ("dst_rows", _ptr), ("pb_off", _ptr),
                 ("pb_len", _ptr), ("items", _ptr), ("n_groups", _i32), ("mt", _i32), ("kt", _i32), ("n_pos", _i32),
                 ("bp", _i32), ("np", _i32), ("n_pblk", _i32), ("n_units", _i32), ("ksplit", _i32), ("xcd_mode", _i32), ("wpos", _i32), ("max_items", _i32), ("max_nc4", _i32), ("src_ts", _i32),
-                ("dst_ts", _i32), ("flags", _i32), ("slope", _f32), ("debug", _ptr), ("bias_idx2", _ptr)]
+                ("dst_ts", _i32), ("flags", _i32), ("slope", _f32), ("debug", _ptr), ("bias_idx2", _ptr), ("act", _ptr),
+                ("act_rows", _ptr)]
 
 
 class Gemm4Desc(C.Structure):
@@ -42,7 +43,8 @@ class Gemm4Desc(C.Structure):
                 ("dst_rows", _ptr), ("pb_off", _ptr), ("pb_len", _ptr), ("items", _ptr), ("scratch", _ptr),
                 ("counters", _ptr), ("n_groups", _i32), ("mtw", _i32), ("nc", _i32), ("kt", _i32), ("n_pos", _i32),
                 ("bp", _i32), ("n_split", _i32), ("n_units", _i32), ("max_items", _i32), ("max_nc32", _i32),
-                ("src_ts", _i32), ("dst_ts", _i32), ("flags", _i32), ("slope", _f32), ("debug", _ptr)]
+                ("src_ts", _i32), ("dst_ts", _i32), ("flags", _i32), ("slope", _f32), ("debug", _ptr), ("act", _ptr),
+                ("act_rows", _ptr)]
 
 
 class Conv3Desc(C.Structure):
@@ -96,6 +98,7 @@ class AdamTensor(C.Structure):
 
 FLAG_LEAKY = 1
 FLAG_ACCUM = 2
+FLAG_LEAKY_GRAD = 4
 PAD_REFLECT = 0
 PAD_ZEROS = 1
 

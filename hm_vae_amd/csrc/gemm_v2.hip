@@ -247,6 +247,14 @@ __global__ __launch_bounds__(512) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
                     }
                     float* dp = d.dst + (size_t)(drow + p * d.dst_ts) * bp + col0 + cu * 64 + (n << 2);
                     if (d.flags & HMVAE_FLAG_ACCUM) s += *(const f32x4*)dp;
+                    if (d.flags & HMVAE_FLAG_LEAKY_GRAD) {
+                        const int arow = d.act_rows ? d.act_rows[g * (MT * 16) + row] : drow;
+                        if (arow >= 0) {
+                            const f32x4 a = *(const f32x4*)(d.act + (size_t)(arow + p * d.dst_ts) * bp + col0 + cu * 64 + (n << 2));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s[e] = a[e] > 0.f ? s[e] : s[e] * d.slope;
+                        }
+                    }
                     *(f32x4*)dp = s;
                 }
         STAMP(3);
@@ -288,6 +296,14 @@ __global__ __launch_bounds__(512) void gather_gemm2_kernel(hmvae_gemm2_desc d) {
             }
             float* dp = d.dst + (size_t)(drow + p * d.dst_ts) * bp + col0 + cu * 64 + (cq << 2);
             if (d.flags & HMVAE_FLAG_ACCUM) s += *(const f32x4*)dp;
+            if (d.flags & HMVAE_FLAG_LEAKY_GRAD) {
+                const int arow = d.act_rows ? d.act_rows[g * (MT * 16) + row] : drow;
+                if (arow >= 0) {
+                    const f32x4 a = *(const f32x4*)(d.act + (size_t)(arow + p * d.dst_ts) * bp + col0 + cu * 64 + (cq << 2));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[e] = a[e] > 0.f ? s[e] : s[e] * d.slope;
+                }
+            }
             *(f32x4*)dp = s;
         }
     }
@@ -311,6 +327,7 @@ static int launch2(const hmvae_gemm2_desc* d, hipStream_t s) {
 
 extern "C" int hmvae_gather_gemm_v2(const hmvae_gemm2_desc* desc, hmvae_stream_t stream) {
     if (!desc || !desc->src || !desc->dst || !desc->wp || !desc->items || (desc->bias && !desc->bias_idx)) return HMVAE_ERR_ARG;
+    if ((desc->flags & HMVAE_FLAG_LEAKY_GRAD) && (!desc->act || (desc->flags & HMVAE_FLAG_LEAKY))) return HMVAE_ERR_ARG;
     if (desc->bp <= 0 || (desc->bp & 63) || desc->n_groups <= 0 || desc->n_pos <= 0 || desc->kt <= 0 || desc->kt > 254)
         return HMVAE_ERR_ARG;
     if (desc->ksplit != 1 && desc->ksplit != 2 && desc->ksplit != 4 && desc->ksplit != 8) return HMVAE_ERR_ARG;

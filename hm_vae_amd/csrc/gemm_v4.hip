@@ -306,6 +306,14 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
         }
         float* dp = d.dst + (size_t)(drow + pb * d.dst_ts) * bp + cb * NC + colbase;
         if (d.flags & HMVAE_FLAG_ACCUM) s += *(const f32x4*)dp;
+        if (d.flags & HMVAE_FLAG_LEAKY_GRAD) {
+            const int arow = d.act_rows ? d.act_rows[g * RP + row_in_group] : drow;
+            if (arow >= 0) {
+                const f32x4 a = *(const f32x4*)(d.act + (size_t)(arow + pb * d.dst_ts) * bp + cb * NC + colbase);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] = a[e] > 0.f ? s[e] : s[e] * d.slope;
+            }
+        }
         *(f32x4*)dp = s;
     };
     // The tile leaves the registers through LDS (the images are free now: every wave is past its last read after the
@@ -509,6 +517,7 @@ extern "C" int hmvae_gather_gemm_v4(const hmvae_gemm4_desc* d, hmvae_stream_t st
         return HMVAE_ERR_ARG;
     if (d->n_groups <= 0 || d->n_pos <= 0 || d->kt <= 0 || d->bp <= 0 || (d->nc != 64 && d->nc != 128) || d->bp % d->nc)
         return HMVAE_ERR_ARG;
+    if ((d->flags & HMVAE_FLAG_LEAKY_GRAD) && (!d->act || (d->flags & HMVAE_FLAG_LEAKY))) return HMVAE_ERR_ARG;
     if (d->mtw != 1 && d->mtw != 2) return HMVAE_ERR_UNSUPPORTED;
     if (d->n_split < 1 || (d->n_split > 1 && (!d->scratch || !d->counters))) return HMVAE_ERR_ARG;
     if (d->max_items <= 0 || d->max_items > V4_MAX_ITEMS || d->max_nc32 <= 0 || d->max_nc32 > V4_MAX_NC32)

@@ -26,6 +26,8 @@ PACK_SPLIT = _os0.environ.get("HMVAE_PACK_SPLIT", "1") != "0"
 # the decoder's / transposed layouts are packed on the early stream BEFORE the targets and the noise are staged there
 LATE_PACK_FIRST = _os0.environ.get("HMVAE_LATE_PACK_FIRST", "1") != "0"
 SHALLOW_SIDE = _os0.environ.get("HMVAE_SHALLOW_SIDE", "1") != "0"
+# LeakyReLU backward of layer i-1 inside the data-gradient GEMM of layer i (HMVAE_FLAG_LEAKY_GRAD) instead of its own launch
+FUSE_LEAKY_BWD = _os0.environ.get("HMVAE_FUSE_LEAKY_BWD", "1") != "0"
 
 
 class VaePlan:
@@ -256,6 +258,8 @@ class VaeEngine(_StepBase):
         self._init_step_base(device)
         self._ws = {}
         self._shallow = None
+        self._cat_act = None
+        self._dp_done = set()
         self._multipack = None
         self._multipack_late = None
         self._multipack_dec = None
@@ -664,13 +668,27 @@ class VaeEngine(_StepBase):
                 self._slice_hook("dec")
         self._backward_encoder(w, phase2, eps, B, bp, enc_w, enc_b, part if part in ("enc_hi", "enc_lo") else "all")
 
+    def _concat_act_base(self):
+        """Row map of the last decoder layer's input (the per-edge concat buffer, seq_two_hier_sa_vae.py:280-288) for the fused
+        LeakyReLU backward: the convolution's rows map to themselves, the skip (latent head) rows to -1."""
+        if self._cat_act is None:
+            p, L = self.p, self.p.L
+            t = p.dec_ts[L - 1]
+            n_src = self.cat_edge_rows // t * p.edge_num[1]                 # channels of the concat buffer
+            ch_per_edge = self.cat_edge_rows // t
+            base = np.arange(n_src, dtype=np.int64) * t
+            skip = (np.arange(n_src) % ch_per_edge) >= self.cD
+            self._cat_act = np.where(skip, -1, base).astype(np.int64)
+        return self._cat_act
+
     def _backward_decoder(self, w, phase2, bp, dconv):
         hp, p, L = self.hp, self.p, self.p.L
         # ---------------- decoder ----------------
+        fused_prev = False          # the previous iteration's data-gradient GEMM already applied this layer's LeakyReLU backward
         for i in range(L - 1, -1, -1):
             t_conv = p.dec_ts[i + 1]
             dy = w["dD%d" % i]
-            if i < L - 1:
+            if i < L - 1 and not fused_prev:
                 if i == L - 2:      # only the conv half of each edge's concat block went through LeakyReLU
                     ops.leaky_bwd(dy, w["D%d" % i], dy, self.cD * t_conv * bp, n_blocks=p.edge_num[1],
                                   block_stride=self.cat_edge_rows * bp)
@@ -682,11 +700,18 @@ class VaeEngine(_StepBase):
                 base = (np.arange(p.dec_cout[i]) * t_conv).astype(np.int32)
                 bias = (dy, dconv[i] + ".bias", ("dconvb", i), base, p.dec_cout[i], t_conv, 1)
             dst = w["dH0"] if i == 0 else w["dD%d" % (i - 1)]
+            fused_prev = False
             if conv.fused_front:
                 src = w["H0"] if i == 0 else w["D%d" % (i - 1)]
                 self._wgrad(conv, dy, w["U%d" % i], dconv[i] + ".weight", bp, w, bias,
                             before=lambda i=i, src=src: self.dec_unpool[i].forward(src, w["U%d" % i], p.dec_ts[i], bp))
-                conv.backward_data(dy, dst, bp)
+                if i >= 1 and FUSE_LEAKY_BWD:
+                    # layer i-1's LeakyReLU backward rides in this launch's epilogue (its output D[i-1] is laid out like dst;
+                    # in the concat buffer only the convolution's half of every edge block went through the activation)
+                    fused_prev = conv.backward_data(dy, dst, bp, act=w["D%d" % (i - 1)],
+                                                    act_base=self._concat_act_base() if i - 1 == L - 2 else None)
+                else:
+                    conv.backward_data(dy, dst, bp)
             else:
                 self._wgrad(conv, dy, w["U%d" % i], dconv[i] + ".weight", bp, w, bias)
                 conv.backward_data(dy, w["dU%d" % i], bp)
@@ -743,7 +768,29 @@ class VaeEngine(_StepBase):
         base = np.arange(2 * d).astype(np.int32)
         self._wgrad(lin, w["dZD%d" % i], w["A%d" % i], "enc.latent_enc_layers.%d.weight" % i, bp, w,
                     (w["dZD%d" % i], "enc.latent_enc_layers.%d.bias" % i, ("elinb", i), base, 2 * d, k, 2 * d))
-        lin.backward_data(w["dZD%d" % i], w["dA%d" % i], bp)
+        self._dp_done = set()        # layers whose dP (gradient behind the LeakyReLU) is already in place
+        self._enc_grad_into(i, lambda dst, **kw: lin.backward_data(w["dZD%d" % i], dst, bp, **kw), w)
+
+    def _enc_fusable(self, i):
+        """Layer i's LeakyReLU backward can ride in the launch that produces its output gradient (the consumer must not
+        need the gradient in front of the activation: pool folded in, weight gradient on the pooled rows)."""
+        c = self.enc_conv[i]
+        return FUSE_LEAKY_BWD and c.fused_pool and c.wg_pooled_dz
+
+    def _enc_grad_into(self, i, launch, w, final=True, accumulate=False):
+        """Run `launch(dst, **kw)` -- a data-gradient GEMM whose result is dL/dA[i] -- so that dP[i] = dL/dA[i] * leaky'(A[i])
+        ends up in w["dP%d" % i] without a launch of its own where that is possible: the GEMM writes dP[i] and applies the
+        factor in its epilogue (`final`: no other launch adds to it later; `accumulate`: this one adds to what is there)."""
+        if not self._enc_fusable(i):
+            launch(w["dA%d" % i], **(dict(accumulate=True) if accumulate else {}))
+            return
+        kw = dict(accumulate=True) if accumulate else {}
+        if not final:
+            launch(w["dP%d" % i], **kw)                       # a later launch accumulates and applies the factor
+            return
+        if not launch(w["dP%d" % i], act=w["A%d" % i], **kw):
+            ops.leaky_bwd(w["dP%d" % i], w["A%d" % i], w["dP%d" % i], w["dP%d" % i].numel())      # (v3 pick: no such epilogue)
+        self._dp_done.add(i)
 
     def _backward_encoder_layers(self, w, phase2, bp, enc_w, enc_b, first, last):
         """Encoder layers first, first-1, .., last (backward order)."""
@@ -755,7 +802,7 @@ class VaeEngine(_StepBase):
                 base = np.arange(2 * d0).astype(np.int32)
                 self._wgrad(lin, w["dZD0"], w["A0"], "enc.latent_enc_layers.0.weight", bp, w,
                             (w["dZD0"], "enc.latent_enc_layers.0.bias", ("elinb", 0), base, 2 * d0, k0, 2 * d0))
-                lin.backward_data(w["dZD0"], w["dA0"], bp, accumulate=True)
+                self._enc_grad_into(0, lambda dst, **kw: lin.backward_data(w["dZD0"], dst, bp, **kw), w, accumulate=True)
             t = p.tsteps[i + 1]
             conv = self.enc_conv[i]
             x = w["X0"] if i == 0 else w["A%d" % (i - 1)]
@@ -764,7 +811,8 @@ class VaeEngine(_StepBase):
             if conv.fused_pool:
                 # gradient w.r.t. the pooled pre-activation: feeds the backward-data GEMM and -- the rows a pool group
                 # averages share their gradient -- the deduplicated weight gradient and the bias sums
-                ops.leaky_bwd(w["dA%d" % i], w["A%d" % i], w["dP%d" % i], w["dA%d" % i].numel())
+                if i not in self._dp_done:
+                    ops.leaky_bwd(w["dA%d" % i], w["A%d" % i], w["dP%d" % i], w["dA%d" % i].numel())
                 if conv.wg_pooled_dz:
                     rows_p = conv.pool_dst_base[conv.pool_rmap].astype(np.int32)
                     bias_p = (w["dP%d" % i], enc_b[i], ("econvbp", i), rows_p, p.enc_cout[i], t, 1,
@@ -775,7 +823,9 @@ class VaeEngine(_StepBase):
                                 before=lambda i=i, t=t: self.enc_pool[i].backward(w["dA%d" % i], w["A%d" % i],
                                                                                   w["dY%d" % i], t, bp))
                 if i > 0:
-                    conv.backward_data(w["dP%d" % i], w["dA%d" % (i - 1)], bp)
+                    # (layer 0 in phase 2: the shallow head's gradient is added afterwards, by the launch that applies the factor)
+                    self._enc_grad_into(i - 1, lambda dst, i=i, **kw: conv.backward_data(w["dP%d" % i], dst, bp, **kw), w,
+                                        final=not (i - 1 == 0 and phase2))
             else:
                 self.enc_pool[i].backward(w["dA%d" % i], w["A%d" % i], w["dY%d" % i], t, bp)
                 self._wgrad(conv, w["dY%d" % i], x, enc_w[i], bp, w, bias)

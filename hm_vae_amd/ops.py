@@ -138,6 +138,8 @@ class _Side:
                              bias_rows2)
         self._last_dense = None
         self._tuned_v4 = {}
+        self._act_now = None
+        self._act_tabs = {}
         # fold = dict(taps [kt][nf], coefs [kt][nf], kt_real, child_tab [n][4] or None, child_side): the packed matrix is a
         # composite one (virtual taps, merged channels; hmvae.h, hmvae_pack_op)
         self.fold = None
@@ -470,7 +472,8 @@ class _Side:
                            _lib.ptr(self.g_ntiles), _lib.ptr(self.chan_rows), _lib.ptr(self.dst_rows), _lib.ptr(pb_off),
                            _lib.ptr(pb_len), _lib.ptr(items), _lib.ptr(scratch), _lib.ptr(counters), g.n_groups, g.mt // 4,
                            int(nc), g.kt, self.n_pos, int(bp), int(split), n_units, max_items, int(g.g_nc4.max()) // 8,
-                           self.src_ts, self.dst_ts, int(flags), float(slope), _lib.ptr(DEBUG_BUF))
+                           self.src_ts, self.dst_ts, int(flags), float(slope), _lib.ptr(DEBUG_BUF),
+                           *((_lib.ptr(self._act_now[0]), _lib.ptr(self._act_now[1])) if self._act_now else (None, None)))
         _lib.check(_lib.load().hmvae_gather_gemm_v4(C.byref(d), _lib.stream()), "gather_gemm_v4")
 
     def _run_incumbent(self, src, dst, bp, bias, flags, slope):
@@ -532,19 +535,51 @@ class _Side:
         if pick is not None:
             MultiPack.refresh(self)
 
-    def run(self, src, dst, bp, bias=None, flags=0, slope=0.2):
+    def _act_table(self, act_base):
+        """Device table [n_groups * rows] of activation row bases for HMVAE_FLAG_LEAKY_GRAD from a map over this side's dense
+        row ids (-1: the row gets no factor), or None = the destination rows themselves."""
+        if act_base is None:
+            return None
+        key = id(act_base)
+        if key not in self._act_tabs:
+            ri = self.g.row_id
+            tab = np.where(ri >= 0, np.asarray(act_base)[np.maximum(ri, 0)], -1).astype(np.int32)
+            self._act_tabs[key] = (_dev(tab, self.device), act_base)          # (the map is kept alive with its table)
+        return self._act_tabs[key][0]
+
+    def run(self, src, dst, bp, bias=None, flags=0, slope=0.2, act=None, act_base=None):
+        """act: fuse the LeakyReLU backward of the layer that produced `act` (laid out like dst) into this launch
+        (HMVAE_FLAG_LEAKY_GRAD).  Returns True if it was fused -- the v3 window kernel has no such epilogue: the launch then
+        runs plain and the caller applies hmvae_leaky_bwd itself."""
         if not USE_V2:
-            return self.run_v1(src, dst, bp, bias, flags, slope)
+            self.run_v1(src, dst, bp, bias, flags, slope)
+            return False
         if KEEP_IO and not torch.cuda.is_current_stream_capturing():
             self._last_io = (src, dst, torch.empty_like(dst))      # tools/tune_in_situ.py times candidates on these
         self.autotune(src, dst, bp, bias, flags, slope)
         p4 = self._tuned_v4.get(bp)
         if p4 is not None and self.tune is None:
-            return self.v4[p4[0]].run_v4(src, dst, bp, bias, flags, slope, p4[1], p4[2])
+            sd = self.v4[p4[0]]
+            if act is not None:
+                sd._act_now = (act, sd._act_table(act_base))
+                flags = int(flags) | _lib.FLAG_LEAKY_GRAD
+            try:
+                sd.run_v4(src, dst, bp, bias, flags, slope, p4[1], p4[2])
+            finally:
+                sd._act_now = None
+            return act is not None
         pick = self._tuned.get(bp)
         if pick is not None and pick[0] == "v3" and self.tune is None:
-            return self.run_v3(src, dst, bp, bias, flags, slope, pick[1], pick[2])
-        return self.run_v2(src, dst, bp, bias, flags, slope)
+            self.run_v3(src, dst, bp, bias, flags, slope, pick[1], pick[2])
+            return False
+        if act is not None:
+            self._act_now = (act, self._act_table(act_base))
+            flags = int(flags) | _lib.FLAG_LEAKY_GRAD
+        try:
+            self.run_v2(src, dst, bp, bias, flags, slope)
+        finally:
+            self._act_now = None
+        return act is not None
 
     def run_v2(self, src, dst, bp, bias=None, flags=0, slope=0.2):
         lib = _lib.load()
@@ -562,7 +597,8 @@ class _Side:
                            _lib.ptr(self.dst_rows), _lib.ptr(pb_off), _lib.ptr(pb_len), _lib.ptr(items), g.n_groups, g.mt,
                            g.kt, self.n_pos, int(bp), np_, n_pblk, n_units, ks, self.xcd_mode(), wpos, max_items, int(g.g_nc4.max()), self.src_ts,
                            self.dst_ts, int(flags),
-                           float(slope), _lib.ptr(DEBUG_BUF), _lib.ptr(self.bias_idx2))
+                           float(slope), _lib.ptr(DEBUG_BUF), _lib.ptr(self.bias_idx2),
+                           *((_lib.ptr(self._act_now[0]), _lib.ptr(self._act_now[1])) if self._act_now else (None, None)))
         _lib.check(lib.hmvae_gather_gemm_v2(C.byref(d), _lib.stream()), "gather_gemm_v2")
 
     def run_v1(self, src, dst, bp, bias=None, flags=0, slope=0.2):
@@ -761,8 +797,10 @@ class MaskedGemm:
     def forward(self, x, y, bp, bias=None, flags=0, slope=0.2):
         self.fwd.run(x, y, bp, bias, flags, slope)
 
-    def backward_data(self, dy, dx, bp, accumulate=False):
-        self.bwd.run(dy, dx, bp, None, _lib.FLAG_ACCUM if accumulate else 0)
+    def backward_data(self, dy, dx, bp, accumulate=False, act=None, act_base=None):
+        """act: also apply the LeakyReLU backward of the layer whose output `act` is (same layout as dx) -- returns True if
+        the launch did it (ops._Side.run), False if the caller still has to."""
+        return self.bwd.run(dy, dx, bp, None, _lib.FLAG_ACCUM if accumulate else 0, act=act, act_base=act_base)
 
     def _k_chunks(self, bp):
         ge = self.geom

@@ -30,6 +30,10 @@ extern "C" {
 
 #define HMVAE_FLAG_LEAKY 1      /* dst = leaky_relu(acc + bias, slope) */
 #define HMVAE_FLAG_ACCUM 2      /* dst += result (read-modify-write) */
+#define HMVAE_FLAG_LEAKY_GRAD 4 /* v2 / v4 gather-GEMMs: dst = (result [+ dst]) * (act > 0 ? 1 : slope) with act read at
+                                   act[act_rows[g,r] + p*dst_ts][b] (act_rows NULL: dst_rows; an entry of -1: factor 1) --
+                                   the LeakyReLU backward of the layer that produced `act`, fused into the data-gradient
+                                   GEMM that writes its output gradient (seq_two_hier_sa_vae.py:129, :250 + autograd) */
 
 #define HMVAE_PAD_REFLECT 0
 #define HMVAE_PAD_ZEROS 1
@@ -99,6 +103,8 @@ typedef struct {
     uint64_t* debug;         /* NULL in production; a diagnostic build (-DHMVAE_STAMP) writes 4 s_memtime stamps per wave */
     const int32_t* bias_idx2;/* NULL, or a second bias index per packed row (-1: none): bias = mean of the two (rows that
                                 are the mean of two dense rows: SkeletonPool folded into the convolution) */
+    const float* act;        /* HMVAE_FLAG_LEAKY_GRAD: the activation tensor (laid out like dst) */
+    const int32_t* act_rows; /* [n_groups*mt*16] act row base per packed row, -1: no factor; NULL: dst_rows */
 } hmvae_gemm2_desc;
 
 int hmvae_gather_gemm_v2(const hmvae_gemm2_desc* desc, hmvae_stream_t stream);
@@ -198,6 +204,8 @@ typedef struct {
     int32_t src_ts, dst_ts, flags;
     float slope;
     uint64_t* debug;         /* NULL in production; a diagnostic build (-DHMVAE_STAMP) writes 8 s_memtime stamps per workgroup */
+    const float* act;        /* HMVAE_FLAG_LEAKY_GRAD, as in hmvae_gemm2_desc */
+    const int32_t* act_rows;
 } hmvae_gemm4_desc;
 
 int hmvae_gather_gemm_v4(const hmvae_gemm4_desc* desc, hmvae_stream_t stream);

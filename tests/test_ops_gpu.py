@@ -190,6 +190,38 @@ def test_skeleton_conv_fwd_bwd(dev, case):
     op.backward_data(gys, dxs, bp, accumulate=True)
     assert rel_err(bct_from_soa(dxs, B, cin, T).numpy(), 2 * x.grad.numpy()) < TOL
 
+    # HMVAE_FLAG_LEAKY_GRAD: the LeakyReLU backward of the layer in front rides in the data-gradient launch's epilogue -- against
+    # the plain launch followed by hmvae_leaky_bwd, bit for bit; with a row map that exempts every third channel; accumulating
+    act = torch.randn(cin * T, bp, device=dev)
+    act_base = np.where(np.arange(cin) % 3 == 2, -1, np.arange(cin) * T).astype(np.int64)
+    exempt = torch.from_numpy(np.repeat(act_base < 0, T)).to(dev)[:, None]
+    plain = torch.empty_like(dxs)
+    op.backward_data(gys, plain, bp)
+    want = torch.empty_like(plain)
+    ops.leaky_bwd(plain, act, want, want.numel())
+    want_map = torch.where(exempt, plain, want)
+    sides = [(op.bwd, lambda sd, o, fl: sd.run_v2(gys, o, bp, None, fl, 0.2))]
+    for sd4, nc, sp in v4_variants(op.bwd, bp):
+        ops.MultiPack(dev).run([(sd4, wd_poison)])
+        sides.append((sd4, lambda sd, o, fl, nc=nc, sp=sp: sd.run_v4(gys, o, bp, None, fl, 0.2, nc, sp)))
+    for sd, launch in sides:
+        ref_plain = torch.empty_like(dxs)
+        launch(sd, ref_plain, 0)
+        ops.leaky_bwd(ref_plain, act, want, want.numel())
+        for tab, expect in ((None, want), (sd._act_table(act_base), torch.where(exempt, ref_plain, want))):
+            got = torch.full_like(dxs, float("nan"))
+            sd._act_now = (act, tab)
+            launch(sd, got, _lib.FLAG_LEAKY_GRAD)
+            assert torch.equal(got, expect), (sd.g.mt, tab is None)
+            launch(sd, got, _lib.FLAG_LEAKY_GRAD | _lib.FLAG_ACCUM)             # (g + got) * f with got = g * f
+            f = torch.where(act > 0, 1.0, 0.2) if tab is None else torch.where(exempt | (act > 0), 1.0, 0.2)
+            assert rel_err(got.cpu().numpy(), ((ref_plain + expect) * f).cpu().numpy()) < 1e-6, (sd.g.mt, tab is None)
+            sd._act_now = None
+    fused = op.backward_data(gys, dxs, bp, act=act, act_base=act_base)            # the public call (the autotuner's pick)
+    assert fused or op.bwd._tuned.get(bp, (0,))[0] == "v3"
+    if fused:
+        assert rel_err(dxs.cpu().numpy(), want_map.cpu().numpy()) < TOL
+
     # the bf16-plane kernel (v4) in every launch shape, forward and backward-data, against the same reference
     lk = _lib.FLAG_LEAKY if case["leaky"] else 0
     check_v4(op.fwd, wd_poison, xs, bp, b.detach().to(dev), lk, y.detach().numpy(),
