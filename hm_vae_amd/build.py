@@ -28,14 +28,14 @@ def build(force=False, verbose=True):
     if extra:
         force = True
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "wreduce_inl.h"), os.path.join(ROOT, "include", "hmvae.h")]
+    deps = srcs + [os.path.join(CSRC, "pack_taps_inl.h"), os.path.join(CSRC, "wreduce_inl.h"), os.path.join(ROOT, "include", "hmvae.h")]
     if not force and not _newer(LIB_PATH, deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     for s in srcs:
         o = os.path.join(LIB_DIR, os.path.basename(s).replace(".hip", ".o"))
-        if force or _newer(o, [s, deps[-1], deps[-2]]):
+        if force or _newer(o, [s] + deps[len(srcs):]):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
                    "-c", s, "-o", o] + extra
             if verbose:

@@ -13,6 +13,7 @@
 // tile are permuted (MFMA tile j, column n  <->  batch column 4n+j) so that one 16-byte load per lane
 // feeds all four 16-column MFMA tiles and the epilogue stores 16 bytes per lane.
 #include <hip/hip_runtime.h>
+#include "pack_taps_inl.h"
 #include <type_traits>
 #include "hmvae.h"
 
@@ -726,7 +727,16 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const hmvae_pack_op* __
             const bool ok = rid >= 0 && cid >= 0 && o.pair_ok[o.g_okoff[g] + r * (nc4 * 4) + c4 * 4 + kk];
             const float* src = o.dense + (ok ? (size_t)rid * o.row_stride + (size_t)cid * o.chan_stride : 0);
             float* dsti = img + st * step_floats + (r >> 4) * 64 + kk * 16 + (r & 15);
-            for (int tap = 0; tap < kt; ++tap) dsti[tap * mt * 64] = ok ? src[(size_t)tap * o.tap_stride] : 0.f;
+            if (HMVAE_PACK_WIDE && kt == 15 && o.tap_stride == 1) {
+                float t[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) t[k] = 0.f;
+                if (ok) hmvae_add_taps15(src, t);
+#pragma unroll
+                for (int tap = 0; tap < 15; ++tap) dsti[tap * mt * 64] = t[tap];
+            } else {
+                for (int tap = 0; tap < kt; ++tap) dsti[tap * mt * 64] = ok ? src[(size_t)tap * o.tap_stride] : 0.f;
+            }
         }
     } else {
         // Composite op.  A thread keeps the (<= 16) real taps of one (row, channel) pair in registers -- summed over the
@@ -765,9 +775,13 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const hmvae_pack_op* __
                     else dc = o.child_tab[cid * 4 + ci];
                 }
                 const float* src = o.dense + (size_t)dr * o.row_stride + (size_t)dc * o.chan_stride;
+                if (HMVAE_PACK_WIDE && kr == 15 && o.tap_stride == 1) {
+                    hmvae_add_taps15(src, t);
+                } else {
 #pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k < kr) t[k] += src[(size_t)k * o.tap_stride];
+                    for (int k = 0; k < 16; ++k)
+                        if (k < kr) t[k] += src[(size_t)k * o.tap_stride];
+                }
             }
             if (bits && o.child_scale) {                       // e.g. 1/2: the packed row is the MEAN of its children
                 const float sc = o.child_scale[o.child_side ? rid : cid];

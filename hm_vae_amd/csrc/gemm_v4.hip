@@ -23,6 +23,7 @@
 // Split K: the K steps of a unit are cut into n_split parts (one workgroup each); the last workgroup of a unit to
 // finish sums the parts in part order (threadfence + counter, no spinning) and runs the epilogue.
 #include <hip/hip_runtime.h>
+#include "pack_taps_inl.h"
 #include <type_traits>
 #include "hmvae.h"
 
@@ -378,28 +379,6 @@ __global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d
 // whole 2 KB fragments.
 constexpr int P4_VC = 8;                       // virtual taps per LDS image
 
-// The 15 taps of one dense (row, channel) pair are 60 contiguous bytes, 4-byte aligned: four 16-byte loads (the last one
-// overlaps the third by a float, so nothing beyond the pair is touched) instead of 15 scalar ones -- every lane of a wave reads
-// another cache line, so the pack is bound by the number of load instructions, not by bytes.
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-#ifdef P4_NARROW                               // timing A/B: the scalar loads of the first version
-constexpr bool P4_WIDE = false;
-#else
-constexpr bool P4_WIDE = true;
-#endif
-__device__ __forceinline__ void add_taps15(const float* __restrict__ src, float (&t)[16]) {
-    const f32x4u a = *(const f32x4u*)src, b = *(const f32x4u*)(src + 4), c = *(const f32x4u*)(src + 8),
-                 d = *(const f32x4u*)(src + 11);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        t[k] += a[k];
-        t[4 + k] += b[k];
-        t[8 + k] += c[k];
-    }
-    t[12] += d[1];
-    t[13] += d[2];
-    t[14] += d[3];
-}
 
 __global__ __launch_bounds__(256) void pack4_kernel(const hmvae_pack_op* __restrict__ ops, int n_ops) {
     extern __shared__ __attribute__((aligned(16))) char simg[];   // [P4_VC][64 lanes][8 floats], then C[kt][16] floats
@@ -463,8 +442,8 @@ __global__ __launch_bounds__(256) void pack4_kernel(const hmvae_pack_op* __restr
                     else dc = o.child_tab[cid[e] * 4 + ci];
                 }
                 const float* src = o.dense + (size_t)dr * o.row_stride + (size_t)dc * o.chan_stride;
-                if (P4_WIDE && kr == 15 && o.tap_stride == 1) {
-                    add_taps15(src, t[e]);
+                if (HMVAE_PACK_WIDE && kr == 15 && o.tap_stride == 1) {
+                    hmvae_add_taps15(src, t[e]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
@@ -490,12 +469,12 @@ __global__ __launch_bounds__(256) void pack4_kernel(const hmvae_pack_op* __restr
             *(u32x4*)(outg + frag * 2048 + (size_t)w16 * 16) = *(const u32x4*)(simg + (size_t)i * 16);
         }
     };
-    if (P4_WIDE && !folded && kt == 15 && o.tap_stride == 1) {               // plain 15-tap convolution: the taps in registers
+    if (HMVAE_PACK_WIDE && !folded && kt == 15 && o.tap_stride == 1) {               // plain 15-tap convolution: the taps in registers
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) t[e][k] = 0.f;
-            if (bits[e]) add_taps15(psrc[e], t[e]);
+            if (bits[e]) hmvae_add_taps15(psrc[e], t[e]);
         }
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
