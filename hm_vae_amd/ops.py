@@ -1426,6 +1426,9 @@ def vae_loss_finalize(mse_partial, kl0_partial, kld_partial, inv_n6, inv_nR, inv
                                                    _lib.ptr(out8), _lib.stream()), "vae_loss_finalize")
 
 
+_ABL_PACK = _os.environ.get("HMVAE_ABL_PACK", "")       # dev: "2", "4" or "24" -- leave those packs out of a captured step
+
+
 class MultiPack:
     """All weight packs of a model as one launch per layout; the descriptor tables are rebuilt only if a tensor moved or a
     side's tuned launches changed the layouts it needs (never inside a stream capture: a side that settles on the v4
@@ -1489,6 +1492,8 @@ class MultiPack:
             self._build(targets, key)
         lib = _lib.load()
         for layout, table, n_ops, total, kmax in self.tables:
+            if _ABL_PACK and str(layout) in _ABL_PACK and torch.cuda.is_current_stream_capturing():
+                continue           # timing ablation (tools/ab_multi.sh): the captured step replays without this pack
             if layout == 4:
                 _lib.check(lib.hmvae_pack_weights_v4(table.data_ptr(), n_ops, total, kmax, _lib.stream()), "pack_weights_v4")
             else:
