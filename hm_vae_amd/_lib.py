@@ -44,7 +44,7 @@ class Gemm4Desc(C.Structure):
                 ("counters", _ptr), ("n_groups", _i32), ("mtw", _i32), ("nc", _i32), ("kt", _i32), ("n_pos", _i32),
                 ("bp", _i32), ("n_split", _i32), ("n_units", _i32), ("max_items", _i32), ("max_nc32", _i32),
                 ("src_ts", _i32), ("dst_ts", _i32), ("flags", _i32), ("slope", _f32), ("debug", _ptr), ("act", _ptr),
-                ("act_rows", _ptr)]
+                ("act_rows", _ptr), ("blk_pos", _ptr), ("pp", _i32), ("n_img", _i32)]
 
 
 class Conv3Desc(C.Structure):

@@ -322,6 +322,171 @@ def build_items(pairs, np_):
     return (np.asarray(pb_off, dtype=np.int32), np.asarray(pb_len, dtype=np.int32), np.asarray(flat, dtype=np.int32))
 
 
+def _pp_blocks(n_pos, pp, pstep):
+    """Blocks of `pp` output positions `pstep` apart (residue classes of pstep, cut into runs of pp)."""
+    blocks = []
+    for r in range(min(pstep, n_pos)):
+        cls = list(range(r, n_pos, pstep))
+        for i in range(0, len(cls), pp):
+            blocks.append(cls[i:i + pp])
+    return blocks
+
+
+def _pp_merge(pairs, block):
+    """Steps of one block: one per (tap, occurrence) of the union of the positions' tap multisets, tap ascending; each
+    step lists the source position of every slot (None = the position does not use this tap occurrence)."""
+    per = []
+    for p in block:
+        by_tap = {}
+        for q, tap in sorted(pairs[p], key=lambda it: (it[1], it[0])):
+            by_tap.setdefault(tap, []).append(q)
+        per.append(by_tap)
+    steps = []
+    for tap in sorted(set(t for bt in per for t in bt)):
+        for k in range(max(len(bt.get(tap, ())) for bt in per)):
+            steps.append((tap, [bt[tap][k] if k < len(bt.get(tap, ())) else None for bt in per]))
+    return steps
+
+
+def _pp_slots(steps, pp, n_img):
+    """Schedule of one block for the v4 kernel with position blocks: the activation rows of a 32-channel step live in
+    n_img LDS images; every emitted step stages AT MOST ONE image (the register ring of the kernel carries one image per
+    step) and multiplies the block's positions with the images that hold their rows.  Returns the emitted steps
+    [(tap | 0xff, load_q | -1, load_slot, [slot per position | 0xf])] or None when n_img images are not enough.
+
+    Rules: an image staged in step e is readable from step e on (stash -> barrier -> multiply) and must not be one that step
+    e - 1 multiplies with (other waves may still be in e - 1) nor one a later step still needs; a step whose rows are not all
+    present after its own load becomes a bubble (tap 0xff: it only stages)."""
+    uses = {}                                    # row -> compute steps that read it
+    for i, (_, qs) in enumerate(steps):
+        for q in qs:
+            if q is not None:
+                uses.setdefault(q, []).append(i)
+    loaded, slot_row = {}, [None] * n_img
+    out, i, prev_read = [], 0, set()
+
+    def next_use(r, i_now):
+        for u in uses[r]:
+            if u >= i_now:
+                return u
+        return None
+
+    def free_slot(i_now, required, before=None):
+        """An image for a new row at compute step i_now: an empty one, else one whose row is not read again, else --
+        for a row the step cannot do without -- the one whose row is read again latest (it is staged again then); a
+        look-ahead load only displaces rows that are read again later than the row it brings (`before`)."""
+        cur = set(q for q in steps[i_now][1] if q is not None)
+        best, best_u = None, -1
+        for s in range(n_img):
+            r = slot_row[s]
+            if s in prev_read or (r is not None and r in cur):
+                continue
+            if r is None:
+                return s
+            u = next_use(r, i_now)
+            if u is None:
+                return s
+            if u > best_u:
+                best, best_u = s, u
+        if best is None:
+            return None
+        if required or (before is not None and best_u > before):
+            return best
+        return None
+
+    guard = 0
+    while i < len(steps):
+        guard += 1
+        if guard > 4 * len(steps) + 64:
+            return None
+        tap, qs = steps[i]
+        need = []
+        for q in qs:
+            if q is not None and q not in loaded and q not in need:
+                need.append(q)
+        load_q, load_s = -1, 0
+        if need:
+            s = free_slot(i, True)
+            if s is None:
+                return None
+            load_q, load_s = need[0], s
+        else:                                    # look ahead: the row a coming step misses first, if an image is free
+            for i2 in range(i + 1, min(len(steps), i + 1 + n_img)):
+                miss = [q for q in steps[i2][1] if q is not None and q not in loaded]
+                if miss:
+                    s = free_slot(i, False, before=i2)
+                    if s is not None:
+                        load_q, load_s = miss[0], s
+                    break
+        if load_q >= 0:
+            old = slot_row[load_s]
+            if old is not None:
+                del loaded[old]
+            slot_row[load_s] = load_q
+            loaded[load_q] = load_s
+        if len(need) <= 1:                       # every row of the step is present now: multiply
+            slots = [0xf if q is None else loaded[q] for q in qs]
+            out.append((tap, load_q, load_s, slots + [0xf] * (4 - len(slots))))
+            prev_read = set(x for x in slots if x != 0xf)
+            i += 1
+        else:
+            out.append((0xff, load_q, load_s, [0xf] * 4))
+            prev_read = set()
+    return out
+
+
+def build_pp_schedule(pairs, pp, max_img=8):
+    """Position blocks for hmvae_gather_gemm_v4 (hmvae_gemm4_desc.pp): `pp` output positions share every weight fragment
+    of a step, and an activation image staged once serves every (position, tap) that reads its source position (for a
+    stride-1 convolution: kt + pp - 1 images per 32 channels instead of pp * kt).
+
+    Returns dict(pp, n_img, blk_pos [n_blk][pp] (-1: no position), blk_off, blk_len, items [n][2] int32 -- word 0 the source
+    position to stage (-1: none), word 1 = tap | load image << 8 | image of position j << (12 + 4j) (0xf: position j sits the
+    step out; tap 0xff: nobody multiplies) --, work = multiplying (step, position) pairs, steps = emitted steps in total) or
+    None.  The positions of a block are `pstep` apart (1, or 2 where neighbouring positions use disjoint taps: transposed
+    stride-2 convolutions, the phases of a folded x2 upsample); the choice with fewer steps wins."""
+    n_pos = len(pairs)
+    assert 1 <= pp <= 4
+    best = None
+    for pstep in ((1,) if pp == 1 else (1, 2)):
+        blocks = _pp_blocks(n_pos, pp, pstep)
+        merged = [_pp_merge(pairs, b) for b in blocks]
+        n_steps = sum(len(m) for m in merged)
+        if best is None or n_steps < best[0]:
+            best = (n_steps, blocks, merged)
+    _, blocks, merged = best
+    # images: the fewest whose schedule is within 3 % of the shortest one found (each image is 12-24 KB of LDS)
+    tried = []
+    for n_img in range(2 if pp == 1 else pp + 1, max_img + 1):
+        sc = [_pp_slots(m, pp, n_img) for m in merged]
+        if all(x is not None for x in sc):
+            tried.append((sum(len(x) for x in sc), n_img, sc))
+            if pp == 1:
+                break
+    if not tried:
+        return None
+    shortest = min(t[0] for t in tried)
+    _, n_img, sched = next(t for t in tried if t[0] <= 1.03 * shortest)
+    blk_pos = np.full((len(blocks), pp), -1, dtype=np.int32)
+    blk_off, blk_len, flat = [], [], []
+    work = 0
+    for bi, (b, sc) in enumerate(zip(blocks, sched)):
+        blk_pos[bi, :len(b)] = b
+        blk_off.append(len(flat))
+        blk_len.append(len(sc))
+        for tap, lq, ls, slots in sc:
+            word = (tap & 0xff) | (ls << 8)
+            for j in range(4):
+                word |= (slots[j] & 0xf) << (12 + 4 * j)
+            flat.append((lq, word))
+            work += sum(1 for x in slots if x != 0xf) if tap != 0xff else 0
+    if max(blk_len) > 256:
+        return None
+    return dict(pp=pp, n_img=n_img, blk_pos=blk_pos, blk_off=np.asarray(blk_off, dtype=np.int32),
+                blk_len=np.asarray(blk_len, dtype=np.int32), items=np.asarray(flat, dtype=np.int32).reshape(-1, 2),
+                work=work, steps=int(sum(blk_len)))
+
+
 def pick_np_ksplit(mt, n_groups, n_pos, n_col_tiles, avg_nc4, target_waves=2048):
     """(64-column units per wave, K split over the waves of a workgroup) for the gather-GEMM.
 

@@ -78,7 +78,15 @@ def v4_variants(side, bp):
             continue
         for nc in (64, 128):
             if bp % nc == 0:
-                out.extend((sd, nc, sp) for sp in (1, 3))
+                out.extend((sd, nc, sp, 1) for sp in (1, 3))
+        # position blocks (hmvae_gemm4_desc.pp): 2 / 4 output positions per unit, weight fragments shared, activation images
+        # scheduled by the planner; unsplit and split over whole 32-channel blocks
+        for pp in (2, 4):
+            if sd.pp_plan(pp) is None:
+                continue
+            for nc in (64, 128):
+                if bp % nc == 0 and (mtw, nc) in sd.V4_PP_SHAPES[pp]:
+                    out.extend((sd, nc, sp, pp) for sp in sorted(set((1, min(2, int(sd.g.g_nc4.min()) // 8)))))
     return out
 
 
@@ -88,18 +96,18 @@ def check_v4(side, dense, src, bp, bias, flags, ref, read_back, what):
     var = v4_variants(side, bp)
     assert var, what
     packed = set()
-    for sd, nc, sp in var:
+    for sd, nc, sp, pp in var:
         if id(sd) not in packed:
             ops.MultiPack(src.device).run([(sd, dense)])
             packed.add(id(sd))
         out = torch.full((read_back[0], bp), float("nan"), device=src.device)
-        sd.run_v4(src, out, bp, bias, flags, 0.2, nc, sp)
-        assert rel_err(read_back[1](out), ref) < TOL, (what, sd.g.mt, nc, sp)
-        if sp == 3 and not (flags & _lib.FLAG_LEAKY):
-            sd.run_v4(src, out, bp, bias, flags | _lib.FLAG_ACCUM, 0.2, nc, sp)
-            assert rel_err(read_back[1](out), 2 * ref) < TOL, (what, "accumulate", sd.g.mt, nc, sp)
-            sd.run_v4(src, out, bp, bias, flags, 0.2, nc, sp)               # counters were left at zero: a third launch agrees
-            assert rel_err(read_back[1](out), ref) < TOL, (what, "relaunch", sd.g.mt, nc, sp)
+        sd.run_v4(src, out, bp, bias, flags, 0.2, nc, sp, pp)
+        assert rel_err(read_back[1](out), ref) < TOL, (what, sd.g.mt, nc, sp, pp)
+        if sp > 1 and not (flags & _lib.FLAG_LEAKY):
+            sd.run_v4(src, out, bp, bias, flags | _lib.FLAG_ACCUM, 0.2, nc, sp, pp)
+            assert rel_err(read_back[1](out), 2 * ref) < TOL, (what, "accumulate", sd.g.mt, nc, sp, pp)
+            sd.run_v4(src, out, bp, bias, flags, 0.2, nc, sp, pp)           # counters were left at zero: a third launch agrees
+            assert rel_err(read_back[1](out), ref) < TOL, (what, "relaunch", sd.g.mt, nc, sp, pp)
 
 
 CONV_CASES = [
@@ -201,10 +209,11 @@ def test_skeleton_conv_fwd_bwd(dev, case):
     ops.leaky_bwd(plain, act, want, want.numel())
     want_map = torch.where(exempt, plain, want)
     sides = [(op.bwd, lambda sd, o, fl: sd.run_v2(gys, o, bp, None, fl, 0.2))]
-    for sd4, nc, sp in v4_variants(op.bwd, bp):
+    for sd4, nc, sp, pp in v4_variants(op.bwd, bp):
         ops.MultiPack(dev).run([(sd4, wd_poison)])
-        sides.append((sd4, lambda sd, o, fl, nc=nc, sp=sp: sd.run_v4(gys, o, bp, None, fl, 0.2, nc, sp)))
-    for sd, launch in sides:
+        sides.append((sd4, lambda sd, o, fl, nc=nc, sp=sp, pp=pp: sd.run_v4(gys, o, bp, None, fl, 0.2, nc, sp, pp), (nc, sp, pp)))
+    sides[0] = sides[0] + ("v2",)
+    for sd, launch, shape in sides:
         ref_plain = torch.empty_like(dxs)
         launch(sd, ref_plain, 0)
         ops.leaky_bwd(ref_plain, act, want, want.numel())
@@ -212,7 +221,7 @@ def test_skeleton_conv_fwd_bwd(dev, case):
             got = torch.full_like(dxs, float("nan"))
             sd._act_now = (act, tab)
             launch(sd, got, _lib.FLAG_LEAKY_GRAD)
-            assert torch.equal(got, expect), (sd.g.mt, tab is None)
+            assert torch.equal(got, expect), (sd.g.mt, tab is None, shape)
             launch(sd, got, _lib.FLAG_LEAKY_GRAD | _lib.FLAG_ACCUM)             # (g + got) * f with got = g * f
             f = torch.where(act > 0, 1.0, 0.2) if tab is None else torch.where(exempt | (act > 0), 1.0, 0.2)
             assert rel_err(got.cpu().numpy(), ((ref_plain + expect) * f).cpu().numpy()) < 1e-6, (sd.g.mt, tab is None)
