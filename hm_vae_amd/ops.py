@@ -24,8 +24,10 @@ USE_V3 = _os.environ.get("HMVAE_V3", "1") != "0"
 # results.  "auto" (default): timed per layer side and batch size against the v2 / v3 pick; "0" never; "1" wherever the
 # kernel supports the problem (first candidate shape).
 USE_V4 = _os.environ.get("HMVAE_V4", "auto")
-# position blocks of the v4 kernel (hmvae_gemm4_desc.pp): candidates of the autotuner unless "0"
-USE_V4_PP = _os.environ.get("HMVAE_V4_PP", "1") != "0"
+# position blocks of the v4 kernel (hmvae_gemm4_desc.pp): candidates of the autotuner only with HMVAE_V4_PP=1 -- measured
+# at 256 and 1024 sequences per GPU no layer side of the shipped configs is faster with them, and every
+# candidate costs tuning time
+USE_V4_PP = _os.environ.get("HMVAE_V4_PP", "0") == "1"
 # Let the autotuner consider the persistent (stream-K) weight-gradient launch.  Off by default: timed alone it wins on
 # most layers, but in the step these GEMMs share the chip with the data-gradient chain and with each other, and workers
 # that hold every CU for their whole launch cost the neighbours more than the balanced tail saves.  A/B on the whole step,

@@ -29,7 +29,7 @@ L = eng.p.L
 names = ["enc%d" % i for i in range(L)] + ["dec%d" % i for i in range(L)]
 convs = eng.enc_conv + eng.dec_conv
 plist = {id(op): wt for op, wt in eng._pack_list()}
-tot2 = tot4 = 0.0
+tot2 = tot4 = tot41 = 0.0
 for name, op in zip(names, convs):
     if only and name not in only:
         continue
@@ -49,7 +49,7 @@ for name, op in zip(names, convs):
         issued2 = 2.0 * side.g.mfma_cost() * n_items * bp
         line = "%s %s: v2 %s %6.1f us %5.1f TF issued (groups %d, items %d)" % (name, sname, side._tuned.get(bp), t2, issued2 / t2 / 1e6, side.g.n_groups, n_items)
         print(line, flush=True)
-        best = None
+        best = best1 = None
         for mtw in (1, 2):
             sd = side.v4_side(mtw)
             if sd is None:
@@ -58,19 +58,25 @@ for name, op in zip(names, convs):
             g4 = sd.g
             issued4 = 2.0 * (g4.g_nc4 * 4).sum() * 16 * g4.mt * n_items * bp      # as if every tile of a group were live
             live = 2.0 * sum(int(nc4) * 4 * 16 * int(nt) for nc4, nt in zip(g4.g_nc4, sd.g_ntiles.cpu().numpy())) * n_items * bp
-            for nc in (128, 64):
-                if bp % nc: continue
-                res = []
-                for sp in sd.v4_splits(bp, nc):
-                    t4 = timeit(lambda: sd.run_v4(src, dst, bp, None, 0, 0.2, nc, sp), reps=8)
-                    res.append((sp, t4))
-                    if best is None or t4 < best[0]:
-                        best = (t4, mtw, nc, sp)
-                print("   v4 mtw %d nc %3d groups %3d wgs/split %4d live-tile flops %5.2f G: %s" % (
-                    mtw, nc, g4.n_groups, g4.n_groups * side.n_pos * (bp // nc), live / 1e9,
-                    "  ".join("S%d %.1f" % r for r in res)), flush=True)
+            for pp in (1, 2, 4):
+                if pp > 1 and sd.pp_plan(pp) is None:
+                    continue
+                for nc in (128, 64):
+                    if bp % nc or (mtw, nc) not in sd.V4_PP_SHAPES[pp]: continue
+                    res = []
+                    for sp in sd.v4_splits(bp, nc, pp):
+                        t4 = timeit(lambda: sd.run_v4(src, dst, bp, None, 0, 0.2, nc, sp, pp), reps=8)
+                        res.append((sp, t4))
+                        if best is None or t4 < best[0]:
+                            best = (t4, mtw, nc, sp, pp)
+                        if pp == 1 and (best1 is None or t4 < best1):
+                            best1 = t4
+                    extra = "" if pp == 1 else " (images %d, steps %d of %d)" % (sd.pp_plan(pp)["n_img"], sd.pp_plan(pp)["steps"], n_items)
+                    print("   v4 mtw %d pp %d nc %3d groups %3d wgs/split %4d live-tile flops %5.2f G: %s%s" % (
+                        mtw, pp, nc, g4.n_groups, g4.n_groups * sd.v4_blocks(pp) * (bp // nc), live / 1e9,
+                        "  ".join("S%d %.1f" % r for r in res), extra), flush=True)
         if best is None:
             continue
-        print("   best v4 %s: %.1f us vs v2 %.1f us  (x%.2f)" % (best[1:], best[0], t2, t2 / best[0]), flush=True)
-        tot2 += t2; tot4 += min(t2, best[0])
-print("sum v2 %.1f us, sum min(v2, v4) %.1f us" % (tot2, tot4))
+        print("   best v4 %s: %.1f us (pp 1: %.1f) vs v2 %.1f us  (x%.2f)" % (best[1:], best[0], best1, t2, t2 / best[0]), flush=True)
+        tot2 += t2; tot4 += min(t2, best[0]); tot41 += min(t2, best1)
+print("sum v2 %.1f us, sum min(v2, v4 without position blocks) %.1f us, sum min(v2, v4) %.1f us" % (tot2, tot41, tot4))
