@@ -74,6 +74,18 @@ class WreduceDesc(C.Structure):
                 ("n_tiles", _i32), ("mt", _i32), ("kt", _i32), ("n_split", _i32), ("row_stride", _i32), ("chan_stride", _i32), ("accumulate", _i32), ("child_tab", _ptr), ("child_scale", _ptr), ("child_side", _i32), ("pad_", _i32), ("tile_part0", _ptr), ("tile_nparts", _ptr)]
 
 
+class BridgeFwdDesc(C.Structure):
+    _fields_ = [("x", _ptr), ("w1", _ptr), ("b1", _ptr), ("eps", _ptr), ("w2", _ptr), ("b2", _ptr), ("dist", _ptr), ("z", _ptr),
+                ("y", _ptr), ("kl_partial", _ptr), ("k_edges", _i32), ("n_in", _i32), ("d", _i32), ("n_out", _i32),
+                ("x_es", _i32), ("y_es", _i32), ("y_off", _i32), ("B", _i32), ("bp", _i32), ("sample", _i32)]
+
+
+class BridgeBwdDesc(C.Structure):
+    _fields_ = [("dy", _ptr), ("w2", _ptr), ("dist", _ptr), ("eps", _ptr), ("w1", _ptr), ("act", _ptr), ("ddist", _ptr),
+                ("dx", _ptr), ("k_edges", _i32), ("n_in", _i32), ("d", _i32), ("n_out", _i32), ("x_es", _i32), ("y_es", _i32),
+                ("y_off", _i32), ("B", _i32), ("bp", _i32), ("flags", _i32), ("kl_scale", _f32), ("slope", _f32)]
+
+
 class PackOp(C.Structure):
     _fields_ = [("dense", _ptr), ("packed", _ptr), ("g_nc4", _ptr), ("g_woff", _ptr), ("g_choff", _ptr), ("chan_id", _ptr),
                 ("row_id", _ptr), ("g_okoff", _ptr), ("pair_ok", _ptr), ("n_groups", _i32), ("max_nc4", _i32), ("mt", _i32),
@@ -126,6 +138,8 @@ _SIGS = {
     "hmvae_aos_to_soa": ([_ptr, _ptr, _i32, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_soa_to_aos": ([_ptr, _ptr, _i32, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_reparam_kl_fwd": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
+    "hmvae_latent_bridge_fwd": ([_ptr, _ptr], _i32),
+    "hmvae_latent_bridge_bwd": ([_ptr, _ptr], _i32),
     "hmvae_reparam_kl_bwd": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),
     "hmvae_fk_fwd": ([_ptr, _i32, _ptr, _i64, C.POINTER(_i32), _i32, _i64, _ptr, _ptr, _ptr], _i32),
     "hmvae_fk_bwd": ([_ptr, _i32, _ptr, _i64, C.POINTER(_i32), _i32, _i64, _ptr, _ptr, _ptr, _ptr], _i32),

@@ -27,6 +27,8 @@ PACK_SPLIT = _os0.environ.get("HMVAE_PACK_SPLIT", "1") != "0"
 LATE_PACK_FIRST = _os0.environ.get("HMVAE_LATE_PACK_FIRST", "1") != "0"
 SHALLOW_SIDE = _os0.environ.get("HMVAE_SHALLOW_SIDE", "1") != "0"
 # LeakyReLU backward of layer i-1 inside the data-gradient GEMM of layer i (HMVAE_FLAG_LEAKY_GRAD) instead of its own launch
+# the latent bridge of a level (head -> reparametrisation + KL -> head) as one launch per direction (latent_bridge.hip)
+FUSE_BRIDGE = _os0.environ.get("HMVAE_FUSE_BRIDGE", "1") != "0"
 FUSE_LEAKY_BWD = _os0.environ.get("HMVAE_FUSE_LEAKY_BWD", "1") != "0"
 
 
@@ -305,6 +307,7 @@ class VaeEngine(_StepBase):
             w["ZD%d" % i], w["dZD%d" % i] = buf(k * 2 * d), buf(k * 2 * d)
             w["Z%d" % i], w["dZ%d" % i] = buf(k * d), buf(k * d)
             w["KLP%d" % i] = torch.zeros(ops.kl_partial_blocks(k, bp, d), device=dev)
+            w["KLPB%d" % i] = torch.zeros(k * (bp // 16), device=dev)          # ... of the one-launch latent bridge
         w["H0"], w["dH0"] = buf(p.edge_num[L] * p.dec_feat[0]), buf(p.edge_num[L] * p.dec_feat[0])
         for i in range(L):
             t_conv = p.dec_ts[i + 1]
@@ -481,6 +484,28 @@ class VaeEngine(_StepBase):
         ops.fk_fwd(rmat, 9, self.offsets, 0, self.parents, B * T, None, w["pos_aos"])
         ops.aos_to_soa(w["pos_aos"], w["GP"], B, T, 72, bp)
 
+    def _bridge_geom(self, i):
+        """(enc head, dec head, dec head's name index, k, d, n_in, n_out, y rows per edge, y offset, y buffer key) of level i's
+        latent bridge, or None when the one-launch kernels do not take it (hmvae_latent_bridge_fwd: d <= 24, d % 4, rows % 64)."""
+        p, L = self.p, self.p.L
+        if not FUSE_BRIDGE or i not in (0, L - 1) or (i == 0 and L == 1):
+            return None
+        k, d, n_in = p.edge_num[i + 1], p.lat_dim[i], p.feat[i]
+        n_out = p.dec_feat[0] if i == L - 1 else p.dec_feat[L - 1]
+        if d > 24 or d % 4 or n_in % 64 or n_out % 64:
+            return None
+        if i == L - 1:
+            return (0, k, d, n_in, n_out, p.dec_feat[0], 0, "H0")
+        return (L - 1, k, d, n_in, n_out, self.cat_edge_rows, self.cD * p.dec_ts[L - 1], "D%d" % (L - 2))
+
+    def _bridge_fwd(self, w, i, eps, sample):
+        P, bp = self.params, w["bp"]
+        di, k, d, n_in, n_out, y_es, y_off, ykey = self._bridge_geom(i)
+        ops.latent_bridge_fwd(w["A%d" % i], P["enc.latent_enc_layers.%d.weight" % i], P["enc.latent_enc_layers.%d.bias" % i],
+                              eps[i], P["dec.latent_dec_layers.%d.weight" % di], P["dec.latent_dec_layers.%d.bias" % di],
+                              w["ZD%d" % i], w["Z%d" % i], w[ykey], w["KLPB%d" % i], k, n_in, d, n_out, n_in, y_es, y_off,
+                              w["B"], bp, sample)
+
     def encode(self, w, heads, after_first=None):
         """after_first: called once layer 0 has been launched (the training step starts the shallow latent branch there)."""
         p, P, bp = self.p, self.params, w["bp"]
@@ -501,14 +526,16 @@ class VaeEngine(_StepBase):
         for i in heads:
             self.enc_lin[i].forward(w["A%d" % i], w["ZD%d" % i], bp, bias=P["enc.latent_enc_layers.%d.bias" % i])
 
-    def decode_feats(self, w, shallow_done=None):
+    def decode_feats(self, w, shallow_done=None, bridged=()):
         """Decoder.forward (seq_two_hier_sa_vae.py:260-294) from Z{L-1} and Z0; result in D{L-1}.
         shallow_done: an event after which the shallow head's part of the concat buffer is in place (the training step
-        computes it on a side stream, see train_step); the last layer waits for it."""
+        computes it on a side stream, see train_step); the last layer waits for it.
+        bridged: levels whose decoder head has already run (the one-launch latent bridge of the training step)."""
         p, P, bp, L = self.p, self.params, w["bp"], self.p.L
         _, _, dconv = self.names()
-        self.dec_lin[0].forward(w["Z%d" % (L - 1)], w["H0"], bp, bias=P["dec.latent_dec_layers.0.bias"])
-        if shallow_done is None:
+        if (L - 1) not in bridged:
+            self.dec_lin[0].forward(w["Z%d" % (L - 1)], w["H0"], bp, bias=P["dec.latent_dec_layers.0.bias"])
+        if shallow_done is None and 0 not in bridged:
             self.dec_lin[L - 1].forward(w["Z0"], w["D%d" % (L - 2)], bp, bias=P["dec.latent_dec_layers.%d.bias" % (L - 1)])
         src = w["H0"]
         for i in range(L):
@@ -541,6 +568,9 @@ class VaeEngine(_StepBase):
         bp = w["bp"]
         phase2 = iterations >= hp["iteration_interval"]
         sample = hp["kl_w"] != 0
+        # levels whose latent bridge is one launch per direction; the noise must exist for the sampling variant
+        bridge = tuple(i for i in sorted(set((0, L - 1))) if self._bridge_geom(i) is not None)
+        self._bridge_levels = bridge
         self._late_packs = []
         self._mid_packs = []
         self._mid_event = None
@@ -611,29 +641,36 @@ class VaeEngine(_StepBase):
                 sb.wait_event(eps_ready)                   # noise + the decoder heads' layouts (early stream)
                 with torch.cuda.stream(sb):
                     k, d = p.edge_num[1], p.lat_dim[0]
-                    self.enc_lin[0].forward(w["A0"], w["ZD0"], bp, bias=P["enc.latent_enc_layers.0.bias"])
-                    ops.reparam_kl_fwd(w["ZD0"], eps[0], w["Z0"], w["KLP0"], k, d, B, bp, sample)
-                    self.dec_lin[L - 1].forward(w["Z0"], w["D%d" % (L - 2)], bp,
-                                                bias=P["dec.latent_dec_layers.%d.bias" % (L - 1)])
+                    if 0 in bridge:
+                        self._bridge_fwd(w, 0, eps, sample)
+                    else:
+                        self.enc_lin[0].forward(w["A0"], w["ZD0"], bp, bias=P["enc.latent_enc_layers.0.bias"])
+                        ops.reparam_kl_fwd(w["ZD0"], eps[0], w["Z0"], w["KLP0"], k, d, B, bp, sample)
+                        self.dec_lin[L - 1].forward(w["Z0"], w["D%d" % (L - 2)], bp,
+                                                    bias=P["dec.latent_dec_layers.%d.bias" % (L - 1)])
                     ev = self._event("shallow_done")
                     ev.record(sb)
                 return ev
             holder = []
-            self.encode(w, (L - 1,), after_first=lambda: holder.append(shallow()))
+            self.encode(w, tuple(i for i in (L - 1,) if i not in bridge), after_first=lambda: holder.append(shallow()))
             shallow_done = holder[0]
         else:
-            self.encode(w, (0, L - 1))
+            self.encode(w, tuple(i for i in (0, L - 1) if i not in bridge))
         if early is not None:
             self._stream_wait(torch.cuda.current_stream(), early, "early_join")
         for i in ((L - 1,) if shallow_done is not None else (0, L - 1)):
+            if i in bridge:
+                self._bridge_fwd(w, i, eps, sample)
+                continue
             k, d = p.edge_num[i + 1], p.lat_dim[i]
             ops.reparam_kl_fwd(w["ZD%d" % i], eps[i], w["Z%d" % i], w["KLP%d" % i], k, d, B, bp, sample)
-        self.decode_feats(w, shallow_done)
+        self.decode_feats(w, shallow_done, bridged=bridge)
         n6, nR, nP = B * T * 144, B * T * 216, B * T * 72
         ops.decode_tail_loss(w["D%d" % (L - 1)], w["X0"], w["GR"], w["GP"], self.offsets, T, B, bp,
                              hp["rec_6d_w"] / n6, hp["rec_rot_w"] / nR, hp["rec_pose_w"] / nP, w["dD%d" % (L - 1)], w["MSEP"])
         ls = w["losses"]
-        ops.vae_loss_finalize(w["MSEP"], w["KLP0"], w["KLP%d" % (L - 1)], 1.0 / n6, 1.0 / nR, 1.0 / nP,
+        ops.vae_loss_finalize(w["MSEP"], w["KLPB0" if 0 in bridge else "KLP0"],
+                              w[("KLPB%d" if (L - 1) in bridge else "KLP%d") % (L - 1)], 1.0 / n6, 1.0 / nR, 1.0 / nP,
                               1.0 / (B * p.edge_num[1]), 1.0 / (B * p.edge_num[L]), hp["rec_6d_w"], hp["rec_rot_w"],
                               hp["rec_pose_w"], hp["kl_w"], hp["shallow_kl_w"], ls)
         if backward:
@@ -660,7 +697,7 @@ class VaeEngine(_StepBase):
         if part in ("all", "dec"):
             self._turn = 0                      # the same chain -> stream assignment every step
             self._pending_red, self._pending_rs = [], []
-            self._backward_decoder(w, phase2, bp, dconv)
+            self._backward_decoder(w, phase2, bp, dconv, bridge=getattr(self, "_bridge_levels", ()))
             if part == "dec":
                 self._join()
                 return
@@ -681,7 +718,9 @@ class VaeEngine(_StepBase):
             self._cat_act = np.where(skip, -1, base).astype(np.int64)
         return self._cat_act
 
-    def _backward_decoder(self, w, phase2, bp, dconv):
+    def _backward_decoder(self, w, phase2, bp, dconv, bridge=()):
+        """bridge: levels whose latent heads' DATA gradients are left to the one-launch bridge of _backward_encoder_head (the
+        training step passes them; callers that stop at the latents' gradients -- the refinement loop -- pass none)."""
         hp, p, L = self.hp, self.p, self.p.L
         # ---------------- decoder ----------------
         fused_prev = False          # the previous iteration's data-gradient GEMM already applied this layer's LeakyReLU backward
@@ -724,13 +763,14 @@ class VaeEngine(_StepBase):
         self._wgrad(lin, dcat, w["Z0"], "dec.latent_dec_layers.%d.weight" % (L - 1), bp, w,
                     (dcat, "dec.latent_dec_layers.%d.bias" % (L - 1), "dlinb_last", base, p.dec_feat[L - 1], p.edge_num[1],
                      self.cat_edge_rows))
-        if phase2:
+        if phase2 and 0 not in bridge:
             lin.backward_data(dcat, w["dZ0"], bp)
         lin = self.dec_lin[0]
         base = np.arange(p.dec_feat[0]).astype(np.int32)
         self._wgrad(lin, w["dH0"], w["Z%d" % (L - 1)], "dec.latent_dec_layers.0.weight", bp, w,
                     (w["dH0"], "dec.latent_dec_layers.0.bias", "dlinb0", base, p.dec_feat[0], p.edge_num[L], p.dec_feat[0]))
-        lin.backward_data(w["dH0"], w["dZ%d" % (L - 1)], bp)
+        if (L - 1) not in bridge:
+            lin.backward_data(w["dH0"], w["dZ%d" % (L - 1)], bp)
 
     def _backward_encoder(self, w, phase2, eps, B, bp, enc_w, enc_b, part="all"):
         hp, p, L = self.hp, self.p, self.p.L
@@ -757,19 +797,39 @@ class VaeEngine(_StepBase):
         hp, p, L = self.hp, self.p, self.p.L
         # ---------------- reparametrisation + KL ----------------
         k, d = p.edge_num[L], p.lat_dim[L - 1]
-        ops.reparam_kl_bwd(w["ZD%d" % (L - 1)], eps[L - 1], w["dZ%d" % (L - 1)], w["dZD%d" % (L - 1)], k, d, B, bp, True,
-                           hp["kl_w"] / (B * k))
-        if phase2:
-            k0, d0 = p.edge_num[1], p.lat_dim[0]
-            ops.reparam_kl_bwd(w["ZD0"], eps[0], w["dZ0"], w["dZD0"], k0, d0, B, bp, True, hp["shallow_kl_w"] / (B * k0))
-        # ---------------- encoder ----------------
+        P = self.params
+        bridge = getattr(self, "_bridge_levels", ())
+        self._dp_done = set()        # layers whose dP (gradient behind the LeakyReLU) is already in place
         i = L - 1
         lin = self.enc_lin[i]
         base = np.arange(2 * d).astype(np.int32)
+        if i in bridge:
+            # decoder head's data gradient -> reparametrisation + KL backward -> encoder head's data gradient (and the last
+            # encoder layer's LeakyReLU backward where its consumer takes the gradient behind the activation): one launch
+            di, _, _, n_in, n_out, y_es, y_off, ykey = self._bridge_geom(i)
+            fus = self._enc_fusable(i)
+            ops.latent_bridge_bwd(w["d" + ykey], P["dec.latent_dec_layers.%d.weight" % di], w["ZD%d" % i], eps[i],
+                                  P["enc.latent_enc_layers.%d.weight" % i], w["dZD%d" % i], w[("dP%d" if fus else "dA%d") % i],
+                                  k, n_in, d, n_out, n_in, y_es, y_off, B, bp, hp["kl_w"] / (B * k),
+                                  act=w["A%d" % i] if fus else None)
+            if fus:
+                self._dp_done.add(i)
+        else:
+            ops.reparam_kl_bwd(w["ZD%d" % i], eps[i], w["dZ%d" % i], w["dZD%d" % i], k, d, B, bp, True, hp["kl_w"] / (B * k))
+        if phase2:
+            k0, d0 = p.edge_num[1], p.lat_dim[0]
+            if 0 in bridge:              # the shallow level: down to the head's pre-activation gradient, layer 0 adds it later
+                di, _, _, n_in, n_out, y_es, y_off, ykey = self._bridge_geom(0)
+                ops.latent_bridge_bwd(w["d" + ykey], P["dec.latent_dec_layers.%d.weight" % di], w["ZD0"], eps[0], None,
+                                      w["dZD0"], None, k0, n_in, d0, n_out, n_in, y_es, y_off, B, bp,
+                                      hp["shallow_kl_w"] / (B * k0))
+            else:
+                ops.reparam_kl_bwd(w["ZD0"], eps[0], w["dZ0"], w["dZD0"], k0, d0, B, bp, True, hp["shallow_kl_w"] / (B * k0))
+        # ---------------- encoder ----------------
         self._wgrad(lin, w["dZD%d" % i], w["A%d" % i], "enc.latent_enc_layers.%d.weight" % i, bp, w,
                     (w["dZD%d" % i], "enc.latent_enc_layers.%d.bias" % i, ("elinb", i), base, 2 * d, k, 2 * d))
-        self._dp_done = set()        # layers whose dP (gradient behind the LeakyReLU) is already in place
-        self._enc_grad_into(i, lambda dst, **kw: lin.backward_data(w["dZD%d" % i], dst, bp, **kw), w)
+        if i not in bridge:
+            self._enc_grad_into(i, lambda dst, **kw: lin.backward_data(w["dZD%d" % i], dst, bp, **kw), w)
 
     def _enc_fusable(self, i):
         """Layer i's LeakyReLU backward can ride in the launch that produces its output gradient (the consumer must not

@@ -1348,6 +1348,26 @@ def reparam_kl_bwd(dist, eps, dz, ddist, k_edges, d, B, bp, use_dz, kl_scale):
                "reparam_kl_bwd")
 
 
+def latent_bridge_fwd(x, w1, b1, eps, w2, b2, dist, z, y, kl_partial, k_edges, n_in, d, n_out, x_es, y_es, y_off, B, bp, sample):
+    """Head -> reparametrisation + KL -> head of one hierarchy level in one launch (hmvae_latent_bridge_fwd)."""
+    assert kl_partial.numel() == k_edges * (bp // 16)
+    dd = _lib.BridgeFwdDesc(_lib.ptr(x), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(eps), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(dist),
+                            _lib.ptr(z), _lib.ptr(y), _lib.ptr(kl_partial), k_edges, n_in, d, n_out, x_es, y_es, y_off, B, bp,
+                            1 if sample else 0)
+    _lib.check(_lib.load().hmvae_latent_bridge_fwd(C.byref(dd), _lib.stream()), "latent_bridge_fwd")
+
+
+def latent_bridge_bwd(dy, w2, dist, eps, w1, ddist, dx, k_edges, n_in, d, n_out, x_es, y_es, y_off, B, bp, kl_scale,
+                      accumulate=False, act=None, slope=0.2):
+    """The backward of latent_bridge_fwd in one launch: ddist is written (the heads' weight gradients read it); dx None stops
+    there; act: the LeakyReLU backward of the layer that produced x rides along (HMVAE_FLAG_LEAKY_GRAD)."""
+    flags = (_lib.FLAG_ACCUM if accumulate else 0) | (_lib.FLAG_LEAKY_GRAD if act is not None else 0)
+    dd = _lib.BridgeBwdDesc(_lib.ptr(dy), _lib.ptr(w2), _lib.ptr(dist), _lib.ptr(eps), _lib.ptr(w1), _lib.ptr(act),
+                            _lib.ptr(ddist), _lib.ptr(dx), k_edges, n_in, d, n_out, x_es, y_es, y_off, B, bp, flags,
+                            float(kl_scale), float(slope))
+    _lib.check(_lib.load().hmvae_latent_bridge_bwd(C.byref(dd), _lib.stream()), "latent_bridge_bwd")
+
+
 def kl_partial_blocks(k_edges, bp, d):
     """Entries of the KL partial-sum buffer written by reparam_kl_fwd: one per (latent component, edge, 256 columns)."""
     return d * k_edges * ((bp + 255) // 256)

@@ -376,6 +376,54 @@ int hmvae_pack_weights_v4(const hmvae_pack_op* ops_dev, int32_t n_ops, int32_t t
                           hmvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The latent bridge of one hierarchy level as one launch per direction: the per-edge nn.Linear head of the Encoder
+ * (seq_two_hier_sa_vae.py:162-170: features -> (mu, logvar)), reparametrize + kl_loss (:359-391) and the per-edge head
+ * of the Decoder (:267-272: z -> features), with the arithmetic of hmvae_reparam_kl_fwd / _bwd in the middle.  The
+ * heads' weights are the dense nn.Linear tensors ([out][in], shared by the edges); rows are SoA ([rows][bp]):
+ *   x    [e * x_es + i]          i < n_in     the encoder's activations of edge e
+ *   dist [e * 2d + r]            r < 2d       (mu | logvar), kept for the backward pass
+ *   z    [e * d + j]             j < d
+ *   y    [e * y_es + y_off + o]  o < n_out    the decoder's input features of edge e
+ * A workgroup owns (edge, 16 batch columns); kl_partial gets one sum per workgroup: [k_edges * bp / 16].
+ * d <= 24 and a multiple of 4, n_in and n_out multiples of 64 (the waves take quarters in 16-row tiles), bp a multiple of 64:
+ * HMVAE_ERR_UNSUPPORTED otherwise (the caller runs the three launches).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* x;
+    const float* w1;         /* [2d][n_in] */
+    const float* b1;         /* [2d] */
+    const float* eps;        /* [B * k_edges][d] noise (sample != 0) */
+    const float* w2;         /* [n_out][d] */
+    const float* b2;         /* [n_out] */
+    float* dist;
+    float* z;
+    float* y;
+    float* kl_partial;
+    int32_t k_edges, n_in, d, n_out, x_es, y_es, y_off, B, bp, sample;
+} hmvae_bridge_fwd_desc;
+
+int hmvae_latent_bridge_fwd(const hmvae_bridge_fwd_desc* desc, hmvae_stream_t stream);
+
+/* Backward: dz = W2^T dy, ddist = kl_scale * d(KL)/d(dist) + the reparametrisation's backward (written: the heads' weight
+ * gradients read it), dx = W1^T ddist -- with HMVAE_FLAG_ACCUM added to what dx holds, with HMVAE_FLAG_LEAKY_GRAD then
+ * multiplied by (act > 0 ? 1 : slope), act laid out like x (the LeakyReLU backward of the layer that produced x).
+ * dx NULL: stop after ddist.  eps NULL: no sampling (z = mu). */
+typedef struct {
+    const float* dy;         /* gradient w.r.t. y, laid out like y */
+    const float* w2;
+    const float* dist;
+    const float* eps;
+    const float* w1;
+    const float* act;
+    float* ddist;            /* laid out like dist */
+    float* dx;               /* laid out like x, or NULL */
+    int32_t k_edges, n_in, d, n_out, x_es, y_es, y_off, B, bp, flags;
+    float kl_scale, slope;
+} hmvae_bridge_bwd_desc;
+
+int hmvae_latent_bridge_bwd(const hmvae_bridge_bwd_desc* desc, hmvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Element-wise / reduction kernels on SoA activations
  * ------------------------------------------------------------------------------------------------ */
 /* SkeletonPool (mean of <=2 edges) + LeakyReLU: skeleton.py:228-231 + seq_two_hier_sa_vae.py:129.

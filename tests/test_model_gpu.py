@@ -168,7 +168,12 @@ def test_decoder_only_sampling_vs_reference(dev, tag):
 
 
 def test_ragged_batch_vs_oracle(dev):
-    """B=70 (not a multiple of 64, more than one 64-column tile) against the CPU oracle, both phases' grads."""
+    """B=70 (not a multiple of 64, more than one 64-column tile) against the CPU oracle, both phases' grads.
+
+    Losses against the oracle in the reference's arithmetic (fp32).  Gradients against the float64 evaluation of the same
+    graph at TOL: on this batch the fp32 oracle ITSELF is 6.0e-5 away from it on dec.latent_dec_layers.3.bias (3.7e-5 on that
+    head's weight, 3.6e-5 on enc.layers.0.0.weight: long sums with cancellation), so a comparison of two fp32 evaluations
+    at 1e-4 measures the reference's rounding as much as ours -- against fp32 they are held to 2 * TOL."""
     cfg, plan, tr, seeded = make_trainer("len64", dev)
     B = 70
     batch = O.synthetic_batch(B, cfg["train_seq_len"], seed=3)
@@ -176,6 +181,9 @@ def test_ragged_batch_vs_oracle(dev):
     orc = O.OracleVAE(cfg, seeded, offsets=offsets())
     it = cfg["iteration_interval"]
     ref = orc.train_forward(batch, it, eps)
+    o64 = O.OracleVAE(cfg, seeded, offsets=offsets(), dtype=torch.float64)
+    o64.train_forward(batch, it, eps)
+    g64 = dict(o64.trainable())
     tr.model.eps_override = eps
     out = tr.model(batch, cfg, it)
     assert rel_err([float(x) for x in out[:5]], [float(ref[k]) for k in ("total", "kl", "rec_6d", "rec_rot", "rec_pose")]) < TOL
@@ -184,7 +192,8 @@ def test_ragged_batch_vs_oracle(dev):
         if p.grad is None:
             assert mine[name].grad is None
             continue
-        assert rel_err(mine[name].grad.cpu().numpy(), p.grad.numpy()) < TOL, name
+        assert rel_err(mine[name].grad.cpu().numpy(), g64[name].grad.numpy()) < TOL, name
+        assert rel_err(mine[name].grad.cpu().numpy(), p.grad.numpy()) < 2 * TOL, name
 
 
 def test_module_composition_matches_oracle(dev):

@@ -485,6 +485,77 @@ def test_reparam_kl(dev, B, k_edges, d):
     assert float(dd[:, B:].abs().max()) == 0.0 if bp > B else True
 
 
+@pytest.mark.parametrize("B,k_edges,n_in,d,n_out,y_es,y_off", [(70, 7, 384, 24, 384, 384, 0), (5, 14, 384, 12, 384, 1152, 768),
+                                                                (130, 3, 64, 8, 128, 140, 8)])
+def test_latent_bridge_one_launch(dev, B, k_edges, n_in, d, n_out, y_es, y_off):
+    """hmvae_latent_bridge_fwd / _bwd: the encoder head (nn.Linear per edge, seq_two_hier_sa_vae.py:162-170), reparametrize +
+    kl_loss (:359-391) and the decoder head (:267-272) of one hierarchy level as one launch per direction, against autograd
+    on the oracle's formulation -- outputs written into a buffer whose edges are y_es rows apart from row y_off (the concat
+    buffer of the last decoder layer), the input gradient plain, accumulated, and with the LeakyReLU backward of the layer in
+    front riding along; padded batch columns stay zero."""
+    from hm_vae_amd import ops
+    torch.manual_seed(B + d)
+    x = torch.randn(B, k_edges, n_in, requires_grad=True)
+    w1 = (torch.randn(2 * d, n_in) / n_in ** 0.5).requires_grad_(True)
+    b1 = (0.1 * torch.randn(2 * d)).requires_grad_(True)
+    w2 = (torch.randn(n_out, d) / d ** 0.5).requires_grad_(True)
+    b2 = (0.1 * torch.randn(n_out)).requires_grad_(True)
+    eps = torch.randn(B * k_edges, d)
+    dist = F.linear(x, w1, b1)
+    mu, lv = dist[:, :, :d].reshape(-1, d), dist[:, :, d:].reshape(-1, d)
+    z = eps * torch.exp(0.5 * lv) + mu
+    kl = O.OracleVAE.kl(lv, mu)
+    y = F.linear(z.reshape(B, k_edges, d), w2, b2)
+    gy = torch.randn_like(y)
+    kl_w = 0.41
+    dist.retain_grad()
+    ((y * gy).sum() + kl_w * kl).backward()
+    xs, bp = soa_from_bct(x.detach().reshape(B, k_edges * n_in, 1), dev)
+    ds = torch.full((k_edges * 2 * d, bp), float("nan"), device=dev)
+    zs = torch.full((k_edges * d, bp), float("nan"), device=dev)
+    ys = torch.full((k_edges * y_es, bp), float("nan"), device=dev)
+    part = torch.full((k_edges * (bp // 16),), float("nan"), device=dev)
+    W1, B1, W2, B2, E = (t.detach().to(dev).contiguous() for t in (w1, b1, w2, b2, eps))
+    ops.latent_bridge_fwd(xs, W1, B1, E, W2, B2, ds, zs, ys, part, k_edges, n_in, d, n_out, n_in, y_es, y_off, B, bp, True)
+    assert rel_err(bct_from_soa(ds, B, k_edges * 2 * d, 1).reshape(B, k_edges, 2 * d).numpy(), dist.detach().numpy()) < 1e-5
+    assert rel_err(bct_from_soa(zs, B, k_edges * d, 1).reshape(B * k_edges, d).numpy(), z.detach().numpy()) < 1e-5
+    yv = ys.reshape(k_edges, y_es, bp)[:, y_off:y_off + n_out, :B].permute(2, 0, 1).cpu()
+    assert rel_err(yv.numpy(), y.detach().numpy()) < 1e-5
+    assert torch.isnan(ys.reshape(k_edges, y_es, bp)[:, :y_off]).all() and torch.isnan(ys.reshape(k_edges, y_es, bp)[:, y_off + n_out:]).all()
+    out = torch.empty(1, device=dev)
+    ops.finalize_sum(part, part.numel(), 1, 0, 1.0 / (B * k_edges), out)
+    assert abs(float(out) - float(kl)) < 1e-5 * max(1.0, abs(float(kl)))
+    if bp > B:
+        assert float(zs[:, B:].abs().max()) == 0.0
+    # no sampling: z = mu
+    ops.latent_bridge_fwd(xs, W1, B1, None, W2, B2, ds, zs, ys, part, k_edges, n_in, d, n_out, n_in, y_es, y_off, B, bp, False)
+    assert rel_err(bct_from_soa(zs, B, k_edges * d, 1).reshape(B * k_edges, d).numpy(), mu.detach().numpy()) < 1e-5
+    ops.latent_bridge_fwd(xs, W1, B1, E, W2, B2, ds, zs, ys, part, k_edges, n_in, d, n_out, n_in, y_es, y_off, B, bp, True)
+    # backward
+    gfull = torch.zeros(B, k_edges, y_es)
+    gfull[:, :, y_off:y_off + n_out] = gy
+    gys, _ = soa_from_bct(gfull.reshape(B, k_edges * y_es, 1), dev)
+    dd = torch.full((k_edges * 2 * d, bp), float("nan"), device=dev)
+    dxs = torch.full((k_edges * n_in, bp), float("nan"), device=dev)
+    scale = kl_w / (B * k_edges)
+    ops.latent_bridge_bwd(gys, W2, ds, E, W1, dd, dxs, k_edges, n_in, d, n_out, n_in, y_es, y_off, B, bp, scale)
+    assert rel_err(bct_from_soa(dd, B, k_edges * 2 * d, 1).reshape(B, k_edges, 2 * d).numpy(), dist.grad.numpy()) < TOL
+    want = x.grad.numpy()
+    assert rel_err(bct_from_soa(dxs, B, k_edges * n_in, 1).reshape(B, k_edges, n_in).numpy(), want) < TOL
+    if bp > B:
+        assert float(dd[:, B:].abs().max()) == 0.0 and float(dxs[:, B:].abs().max()) == 0.0
+    ops.latent_bridge_bwd(gys, W2, ds, E, W1, dd, dxs, k_edges, n_in, d, n_out, n_in, y_es, y_off, B, bp, scale, accumulate=True)
+    assert rel_err(bct_from_soa(dxs, B, k_edges * n_in, 1).reshape(B, k_edges, n_in).numpy(), 2 * want) < TOL
+    act = torch.randn(k_edges * n_in, bp, device=dev)
+    ops.latent_bridge_bwd(gys, W2, ds, E, W1, dd, dxs, k_edges, n_in, d, n_out, n_in, y_es, y_off, B, bp, scale, act=act)
+    f = torch.where(act > 0, 1.0, 0.2)[:, :B].reshape(k_edges, n_in, B).permute(2, 0, 1).cpu().numpy()
+    assert rel_err(bct_from_soa(dxs, B, k_edges * n_in, 1).reshape(B, k_edges, n_in).numpy(), want * f) < TOL
+    # dx NULL: stop at the head's pre-activation gradient
+    dd2 = torch.full_like(dd, float("nan"))
+    ops.latent_bridge_bwd(gys, W2, ds, E, None, dd2, None, k_edges, n_in, d, n_out, n_in, y_es, y_off, B, bp, scale)
+    assert torch.equal(dd2, dd)
+
+
 def test_fk_against_reference_golden(dev):
     """AoS kernels vs vectors produced by the unmodified reference (tests/golden/fk_rot6d.npz)."""
     from hm_vae_amd import ops
