@@ -871,7 +871,9 @@ class VaeEngine(_StepBase):
             if conv.fused_pool:
                 # gradient w.r.t. the pooled pre-activation: feeds the backward-data GEMM and -- the rows a pool group
                 # averages share their gradient -- the deduplicated weight gradient and the bias sums
-                if i not in self._dp_done:
+                # (layer 0 without the pooled weight gradient: nothing reads dP -- no data gradient is wanted and the weight
+                # gradient takes dY from the pool's own backward)
+                if i not in self._dp_done and (i > 0 or conv.wg_pooled_dz):
                     ops.leaky_bwd(w["dA%d" % i], w["A%d" % i], w["dP%d" % i], w["dA%d" % i].numel())
                 if conv.wg_pooled_dz:
                     rows_p = conv.pool_dst_base[conv.pool_rmap].astype(np.int32)
