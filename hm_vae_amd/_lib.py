@@ -138,6 +138,7 @@ _SIGS = {
     "hmvae_aos_to_soa": ([_ptr, _ptr, _i32, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_soa_to_aos": ([_ptr, _ptr, _i32, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_reparam_kl_fwd": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
+    "hmvae_randn": ([_ptr, _i64, C.c_uint64, _ptr, _ptr], _i32),
     "hmvae_latent_bridge_fwd": ([_ptr, _ptr], _i32),
     "hmvae_latent_bridge_bwd": ([_ptr, _ptr], _i32),
     "hmvae_reparam_kl_bwd": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _f32, _ptr], _i32),

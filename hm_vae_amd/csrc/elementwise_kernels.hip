@@ -428,6 +428,69 @@ extern "C" int hmvae_reparam_kl_bwd(const float* dist, const float* eps, const f
     return LAUNCH_OK();
 }
 
+// ---------------- standard-normal noise for the reparametrisation (seq_two_hier_sa_vae.py:359-366: torch.randn_like) ----------------
+// Philox4x32-10 (counter = element index / 4 and the launch count, key = seed) + Box-Muller, four values per thread.  The
+// launch count lives on the device (state[0]) and is advanced by the LAST workgroup to finish -- every workgroup reads it
+// first, so a captured graph draws fresh noise at every replay without a host-side seed update in front of it (torch's
+// generator costs two scalar fill launches before every replay of a graph that holds torch.randn, and one launch per level).
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, long long n, unsigned long long seed,
+                                                    unsigned long long* __restrict__ state) {
+    __shared__ unsigned long long s_launch;
+    __shared__ int s_last;
+    if (threadIdx.x == 0) s_launch = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned long long launch = s_launch;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; 4 * q < n; q += (long long)gridDim.x * 256) {
+        unsigned c[4] = {(unsigned)q, (unsigned)((unsigned long long)q >> 32), (unsigned)launch, (unsigned)(launch >> 32)};
+        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = (float)(c[2 * h] >> 8) * 5.9604645e-8f + 2.9802322e-8f;       // (0, 1)
+            const float u2 = (float)(c[2 * h + 1] >> 8) * 5.9604645e-8f;                   // [0, 1)
+            const float rad = sqrtf(-2.f * logf(u1));
+            float sn, cs;
+            sincosf(6.2831853071795865f * u2, &sn, &cs);
+            z[2 * h] = rad * cs;
+            z[2 * h + 1] = rad * sn;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * q + e < n) out[4 * q + e] = z[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long done = __hip_atomic_fetch_add(state + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = done == (unsigned long long)gridDim.x - 1;
+        if (s_last) {
+            __hip_atomic_store(state + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(state, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+extern "C" int hmvae_randn(float* out, int64_t n, uint64_t seed, uint64_t* state, hmvae_stream_t stream) {
+    if (!out || !state || n <= 0) return HMVAE_ERR_ARG;
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, (long long)n,
+                       (unsigned long long)seed, (unsigned long long*)state);
+    return LAUNCH_OK();
+}
+
 // ---------------- fixed-order final sums ----------------
 __global__ __launch_bounds__(256) void finalize_sums_kernel(const float* __restrict__ partial, int n_partial, int stride,
                                                              int k, float scale, float* __restrict__ out) {

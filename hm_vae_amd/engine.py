@@ -28,6 +28,9 @@ LATE_PACK_FIRST = _os0.environ.get("HMVAE_LATE_PACK_FIRST", "1") != "0"
 SHALLOW_SIDE = _os0.environ.get("HMVAE_SHALLOW_SIDE", "1") != "0"
 # LeakyReLU backward of layer i-1 inside the data-gradient GEMM of layer i (HMVAE_FLAG_LEAKY_GRAD) instead of its own launch
 # the latent bridge of a level (head -> reparametrisation + KL -> head) as one launch per direction (latent_bridge.hip)
+# the reparametrisation's noise from hmvae_randn (one launch, device-side launch counter) instead of torch.randn per level: a
+# graph that holds torch.randn makes torch fill two RNG scalars in front of every replay ("torch": the torch generator)
+NOISE_HIP = _os0.environ.get("HMVAE_NOISE", "hip") != "torch"
 FUSE_BRIDGE = _os0.environ.get("HMVAE_FUSE_BRIDGE", "1") != "0"
 FUSE_LEAKY_BWD = _os0.environ.get("HMVAE_FUSE_LEAKY_BWD", "1") != "0"
 
@@ -260,6 +263,7 @@ class VaeEngine(_StepBase):
         self._init_step_base(device)
         self._ws = {}
         self._shallow = None
+        self._noise_state = None
         self._cat_act = None
         self._dp_done = set()
         self._multipack = None
@@ -606,10 +610,24 @@ class VaeEngine(_StepBase):
                 self._multipack_late.run(self._late_packs)
                 self._late_packs = []
             self.stage_targets(w, rmat)
+            if eps_list is None and sample and NOISE_HIP:
+                # the two levels that are sampled (the middle heads feed nothing), one launch, the launch counter on the device
+                if "EPS" not in w:
+                    n0, nd = B * p.edge_num[1] * p.lat_dim[0], B * p.edge_num[L] * p.lat_dim[L - 1]
+                    w["EPS"] = torch.empty(n0 + (nd if L > 1 else 0), device=self.device)
+                    w["EPS_views"] = {0: w["EPS"][:n0].view(B * p.edge_num[1], p.lat_dim[0])}
+                    if L > 1:
+                        w["EPS_views"][L - 1] = w["EPS"][n0:].view(B * p.edge_num[L], p.lat_dim[L - 1])
+                if self._noise_state is None:
+                    self._noise_state = torch.zeros(2, dtype=torch.int64, device=self.device)
+                    self._noise_seed = torch.initial_seed()
+                ops.randn_(w["EPS"], self._noise_seed, self._noise_state)
             for i in range(L):
                 k, d = p.edge_num[i + 1], p.lat_dim[i]
                 if eps_list is not None:
                     e = eps_list[i]
+                elif sample and NOISE_HIP:
+                    e = w["EPS_views"].get(i)
                 elif sample:
                     e = torch.randn(B * k, d, device=self.device)
                 else:

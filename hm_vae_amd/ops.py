@@ -1348,6 +1348,12 @@ def reparam_kl_bwd(dist, eps, dz, ddist, k_edges, d, B, bp, use_dz, kl_scale):
                "reparam_kl_bwd")
 
 
+def randn_(out, seed, state):
+    """out <- standard-normal noise (hmvae_randn); state: int64[2] device tensor, zeros at first, advanced by every launch."""
+    _lib.check(_lib.load().hmvae_randn(_lib.ptr(out), out.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, state.data_ptr(),
+                                       _lib.stream()), "randn")
+
+
 def latent_bridge_fwd(x, w1, b1, eps, w2, b2, dist, z, y, kl_partial, k_edges, n_in, d, n_out, x_es, y_es, y_off, B, bp, sample):
     """Head -> reparametrisation + KL -> head of one hierarchy level in one launch (hmvae_latent_bridge_fwd)."""
     assert kl_partial.numel() == k_edges * (bp // 16)

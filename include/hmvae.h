@@ -466,6 +466,11 @@ int hmvae_row_sums_multi(const hmvae_rowsum_op* ops_dev, int32_t n_ops, int32_t 
 int hmvae_aos_to_soa(const float* aos, float* soa, int32_t B, int32_t T, int32_t C, int32_t bp, hmvae_stream_t stream);
 int hmvae_soa_to_aos(const float* soa, float* aos, int32_t B, int32_t T, int32_t C, int32_t bp, hmvae_stream_t stream);
 
+/* n standard-normal floats (the reparametrisation's noise, seq_two_hier_sa_vae.py:359-366 torch.randn_like): Philox4x32-10
+ * keyed by `seed`, counter = (element / 4, launch count) + Box-Muller.  state[0] = launch count, state[1] = scratch (both
+ * zero at first; the launch advances state[0] itself, so a captured graph draws fresh noise at every replay). */
+int hmvae_randn(float* out, int64_t n, uint64_t seed, uint64_t* state, hmvae_stream_t stream);
+
 /* reparametrize + KL: seq_two_hier_sa_vae.py:419-428.
  * dist rows: (e*2d + j) mu, (e*2d + d + j) logvar, [rows][bp]; eps AoS (B*k, d); z rows (e*d + j).
  * kl_partial[(j * k_edges + e) * ceil(bp/256) + block] = sum over the block's columns of -0.5*(1 + lv - mu^2 - exp(lv))

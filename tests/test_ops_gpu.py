@@ -556,6 +556,46 @@ def test_latent_bridge_one_launch(dev, B, k_edges, n_in, d, n_out, y_es, y_off):
     assert torch.equal(dd2, dd)
 
 
+def test_randn_kernel_statistics(dev):
+    """hmvae_randn: Philox4x32-10 + Box-Muller with the launch counter on the device -- moments of a standard normal, a fresh
+    draw at every launch (also when the launch is replayed from a hipGraph), the same stream again from the same seed and
+    counter, nothing written past n."""
+    from hm_vae_amd import ops
+    n = 1 << 20
+    out = torch.full((n + 8,), 7.0, device=dev)
+    state = torch.zeros(2, dtype=torch.int64, device=dev)
+    ops.randn_(out[:n], 1234, state)
+    a = out[:n].double().cpu().numpy()
+    assert (out[n:] == 7.0).all() and state.tolist() == [1, 0]
+    assert abs(a.mean()) < 5e-3 and abs(a.var() - 1) < 1e-2 and abs((a ** 3).mean()) < 2e-2 and abs((a ** 4).mean() - 3) < 5e-2
+    assert abs(np.corrcoef(a[:-1], a[1:])[0, 1]) < 5e-3 and abs(np.corrcoef(a[:-4], a[4:])[0, 1]) < 5e-3
+    assert np.abs(a).max() < 6.5 and len(np.unique(a)) > 0.9 * n
+    ops.randn_(out[:n], 1234, state)
+    b = out[:n].double().cpu().numpy()
+    assert state.tolist() == [2, 0] and abs(np.corrcoef(a, b)[0, 1]) < 5e-3
+    state.zero_()
+    ops.randn_(out[:n], 1234, state)
+    assert np.array_equal(out[:n].double().cpu().numpy(), a)                 # same seed, same counter: the same stream
+    ops.randn_(out[:n], 99, state.zero_())
+    assert abs(np.corrcoef(a, out[:n].double().cpu().numpy())[0, 1]) < 5e-3  # another seed
+    small = torch.zeros(10, device=dev)
+    ops.randn_(small[:7], 5, state)
+    assert (small[7:] == 0).all() and (small[:7] != 0).all()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.randn_(out[:n], 1234, state)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        ops.randn_(out[:n], 1234, state)
+    g.replay()
+    c1 = out[:n].clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert abs(np.corrcoef(c1.cpu().numpy(), out[:n].cpu().numpy())[0, 1]) < 5e-3
+
+
 def test_fk_against_reference_golden(dev):
     """AoS kernels vs vectors produced by the unmodified reference (tests/golden/fk_rot6d.npz)."""
     from hm_vae_amd import ops
