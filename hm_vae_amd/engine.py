@@ -620,7 +620,9 @@ class VaeEngine(_StepBase):
                         w["EPS_views"][L - 1] = w["EPS"][n0:].view(B * p.edge_num[L], p.lat_dim[L - 1])
                 if self._noise_state is None:
                     self._noise_state = torch.zeros(2, dtype=torch.int64, device=self.device)
-                    self._noise_seed = torch.initial_seed()
+                    # (one stream per rank: the ranks of a data-parallel job are usually seeded alike)
+                    from . import ddp as _ddp
+                    self._noise_seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * _ddp.rank()) & 0xFFFFFFFFFFFFFFFF
                 ops.randn_(w["EPS"], self._noise_seed, self._noise_state)
             for i in range(L):
                 k, d = p.edge_num[i + 1], p.lat_dim[i]
