@@ -485,7 +485,7 @@ def test_reparam_kl(dev, B, k_edges, d):
     assert float(dd[:, B:].abs().max()) == 0.0 if bp > B else True
 
 
-@pytest.mark.parametrize("B,k_edges,n_in,d,n_out,y_es,y_off", [(70, 7, 384, 24, 384, 384, 0), (5, 14, 384, 12, 384, 1152, 768),
+@pytest.mark.parametrize("B,k_edges,n_in,d,n_out,y_es,y_off", [(256, 7, 384, 24, 384, 384, 0), (70, 7, 384, 24, 384, 384, 0), (5, 14, 384, 12, 384, 1152, 768),
                                                                 (130, 3, 64, 8, 128, 140, 8)])
 def test_latent_bridge_one_launch(dev, B, k_edges, n_in, d, n_out, y_es, y_off):
     """hmvae_latent_bridge_fwd / _bwd: the encoder head (nn.Linear per edge, seq_two_hier_sa_vae.py:162-170), reparametrize +
