@@ -8,11 +8,11 @@
 // head) of a few microseconds each, and six in the backward pass -- 66 MFLOP in all, but serial and with a queue hand-over
 // between every two: replaying the step without them is 45-70 us (3-5 %) shorter (tools/abl_step.py).  Every edge is
 // independent (the heads' weights are shared by the edges, each edge's feature vector maps to its own latent), so a
-// workgroup owns (edge, 64 batch columns) and walks the whole chain with the intermediate tiles in LDS:
-//   forward   dist = W1 x + b1 (2d x 64)  ->  z = mu + eps * exp(logvar / 2), KL partial  ->  y = W2 z + b2
+// workgroup owns (edge, 16 batch columns) and walks the whole chain with the intermediate tiles in LDS:
+//   forward   dist = W1 x + b1 (2d x 16)  ->  z = mu + eps * exp(logvar / 2), KL partial  ->  y = W2 z + b2
 //   backward  dz = W2^T dy  ->  ddist = d(KL) + reparametrisation backward  ->  dx = W1^T ddist (+= / * leaky'(act))
-// Plain fp32 FMAs on the vector pipe: the matrices are 48 x 384 and 384 x 24 -- a thread keeps one batch column and a
-// quarter of the output rows, the weights are wave-uniform scalar loads (rows of eight consecutive floats).
+// The three small products (48 x 384, 384 x 24 and their transposes) run on the fp32 matrix pipe; how the kernels got from
+// 160-270 us per launch (fp32 FMAs, scalar weight loads) to 8-9 us is told in front of the kernels and in DESIGN.md 7.
 #include <hip/hip_runtime.h>
 #include "hmvae.h"
 
