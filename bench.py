@@ -25,6 +25,18 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2516.6    # same guide: bf16 MFMA = 16x the fp32 rate (~2.5 PFLOP/s dense)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.3 TB/s achievable with a float4 copy)
+# fp32-grade products on the bf16 pipe cost SIX bf16 MFMAs per fp32-equivalent block (three exact planes per operand, the
+# six significant cross terms): the ceiling of such a launch in fp32-equivalent terms
+PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+
+
+def effective_peak(pipe_ms):
+    """Time-weighted ceiling of a kernel family that mixes the two pipes: launches that run three-plane bf16 MFMAs are
+    priced at 2516.6 / 6 = 419.4 TFLOP/s (fp32-equivalent), plain fp32 MFMA launches (and the reduce launches) at 157.3."""
+    tot = pipe_ms["bf16x3"] + pipe_ms["fp32"]
+    if tot <= 0:
+        return PEAK_F32_MFMA_TFLOPS
+    return (pipe_ms["bf16x3"] * PEAK_BF16X3_TFLOPS + pipe_ms["fp32"] * PEAK_F32_MFMA_TFLOPS) / tot
 
 
 def synthetic_device_batch(B, T, seed, device):
@@ -48,15 +60,18 @@ class KernelTimer:
     def __init__(self):
         self.records = []
         self.current = None            # (label, useful flops, issued flops) of the operator being launched
+        self.pipe = None               # "bf16x3" / "fp32" of the operator being launched, or None = by entry point
 
-    def wrap_op(self, obj, name, label, flops_fn):
-        """Python-level: tags the launches made inside obj.name(...) with a family label and their flops."""
+    def wrap_op(self, obj, name, label, flops_fn, pipe_fn=None):
+        """Python-level: tags the launches made inside obj.name(...) with a family label and their flops.
+        pipe_fn(*args) -> "bf16x3" | "fp32": the matrix pipe the operator's launches run on (None: by entry point)."""
         orig = getattr(obj, name)
         timer = self
 
         def tagged(*a, **k):
             fl = flops_fn(*a, **k)
             timer.current = [label] + list(fl if isinstance(fl, tuple) else (fl, fl))
+            timer.pipe = pipe_fn(*a, **k) if pipe_fn is not None else None
             try:
                 return orig(*a, **k)
             finally:
@@ -78,7 +93,8 @@ class KernelTimer:
             r = orig(*a)
             e1.record()
             label, fl, issued = timer.current
-            timer.records.append((label, name, e0, e1, fl, issued))
+            pipe = timer.pipe or ("bf16x3" if name == "hmvae_gather_gemm_v4" else "fp32")
+            timer.records.append((label, name, e0, e1, fl, issued, pipe))
             timer.current[1] = timer.current[2] = 0.0
             return r
 
@@ -88,13 +104,16 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg, per_kernel = {}, {}
-        for label, cname, e0, e1, fl, issued in self.records:
+        self.pipe_ms = {}                  # label -> {"bf16x3": ms, "fp32": ms}
+        for label, cname, e0, e1, fl, issued, pipe in self.records:
             ms = e0.elapsed_time(e1)
             a = agg.setdefault(label, [0.0, 0.0, 0, 0.0])
             a[0] += ms
             a[1] += fl
             a[2] += 1
             a[3] += issued
+            pm = self.pipe_ms.setdefault(label, {"bf16x3": 0.0, "fp32": 0.0})
+            pm[pipe] += ms
             k = per_kernel.setdefault(cname, [0.0, 0, 0.0, 0.0])
             k[0] += ms
             k[1] += 1
@@ -132,7 +151,8 @@ def instrument_gemms(engine, timer, bp):
                                                        (_f * a[2], issued_per_col(_s, a[2]) * a[2]) if len(a) > 2 else (0.0, 0.0))))
         restore.append((op, "backward_weight", timer.wrap_op(op, "backward_weight",
                                                              "wgrad (wgrad_bf3_kernel | wgrad_lds_kernel | wgrad_kernel | wreduce_kernel)",
-                                                             lambda *a, _f=useful_f, **k: _f * a[3])))
+                                                             lambda *a, _f=useful_f, **k: _f * a[3],
+                                                             pipe_fn=lambda *a, _o=op, **k: "bf16x3" if _o.wg_mode(a[3]) in (2, 3) else "fp32")))
     lib = _lib.load()
     for cname in ("hmvae_gather_gemm_v2", "hmvae_gather_gemm_v3", "hmvae_gather_gemm_v4", "hmvae_wgrad_gemm", "hmvae_wgrad_reduce"):
         restore.append((lib, cname, timer.wrap_c(lib, cname)))
@@ -246,7 +266,8 @@ def fk_microbench(device, iters=20):
             "bytes_per_frame_algorithmic": fused_bytes, "avg_us": avg * 1e3,
             "traffic": traffic_of("decode_tail_fwd_kernel<false>"),
             "fk_bwd_aos": entry("fk_bwd_aos_kernel<6>", 2304, avg4, "backward of the fused lift + FK, frame-major"),
-            "tail_loss": entry("decode_tail_loss_kernel<false>", 2880, avg5,
+            "tail_loss": entry("decode_tail_loss_kernel<false>" if os.environ.get("HMVAE_TAIL3", "1") == "0" else
+                               "decode_tail_loss3_kernel<false>", 2880, avg5,
                                "training tail (lift + FK + 3 MSE + their backward) at config 4's frame count"),
             "note": "6D (SoA) in, R + positions (frame-major) out: the bytes moved are the algorithmic 1728 B/frame",
             "with_6d_copy": {"kernel": "decode_tail_fwd_kernel<true>", "bytes_per_frame_moved": 2304, "avg_us": avg_c6 * 1e3,
@@ -257,6 +278,101 @@ def fk_microbench(device, iters=20):
                                      "write; achieved / frac count SURVEY's 1728 algorithmic bytes only"},
             "fk_only_aos": entry("fk_fwd_aos_kernel<9>", 1152, avg2, "ForwardKinematicsLayer on rotation matrices"),
             "fk_rot6d_aos": entry("fk_fwd_aos_kernel<6>", 864, avg3, "6D in, positions out")}
+
+
+def sampling_bench(tr, cfg, device, iters=10):
+    """BASELINE config 4 end to end: decoder-only sampling, z-list randn (4096,14,12), (4096,9,24), (4096,7,24) x 2 ->
+    TwoHierSAVAEModel._decode (seq_two_hier_sa_vae.py:609-610,629-632 -> :436-474) -> 6D, R, joint positions for 262 144
+    frames.  The latents are resident in HBM; the call is the API's (weight layouts re-packed, outputs allocated)."""
+    from hm_vae_amd import _lib
+    B = 4096
+    model = tr.model
+    eng = model.engine()
+    p = eng.p
+    g = torch.Generator(device="cpu").manual_seed(4)
+    zl = [torch.randn(B, p.edge_num[i + 1], p.lat_dim[i], generator=g).to(device) for i in range(p.L)]
+    for _ in range(2):
+        model._decode(zl)                      # warm-up: workspace, launch shapes of the 4096-column problems
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        model._decode(zl)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    # the decoder's four forward convolutions alone: HIP events around their C-ABI launches, two more calls
+    timer = KernelTimer()
+    restore = []
+    fl = 0.0
+    for op in eng.dec_conv:
+        f = 2.0 * op.useful_macs_per_col
+        fl += f * B
+        restore.append((op.fwd, "run", timer.wrap_op(op.fwd, "run", "decoder forward convolutions",
+                                                     lambda *a, _f=f, **k: _f * B)))
+    lib = _lib.load()
+    for cname in ("hmvae_gather_gemm_v2", "hmvae_gather_gemm_v3", "hmvae_gather_gemm_v4"):
+        restore.append((lib, cname, timer.wrap_c(lib, cname)))
+    n_inst = 2
+    for _ in range(n_inst):
+        model._decode(zl)
+    agg = timer.summary()
+    for obj, name, orig in restore:
+        setattr(obj, name, orig)
+    cms = agg["decoder forward convolutions"][0] / n_inst
+    peff = effective_peak(timer.pipe_ms["decoder forward convolutions"])
+    bp = eng.workspace(B)["bp"]
+
+    def pick(side):
+        if side._tuned_v4.get(bp) is not None:
+            return "v4"
+        t = side._tuned.get(bp)
+        return "v3" if (t and t[0] == "v3") else "v2"
+    picks = [pick(op.fwd) for op in eng.dec_conv]
+    out = {"workload": "len_64_test_interpolation.yaml decoder-only sampling, batch 4096: z-list -> _decode -> 6D, R, positions",
+           "value": B / (ms * 1e-3), "unit": "sequences/s", "ms_per_call": ms, "frames": B * p.T, "calls": iters,
+           "decoder_forward": {"ms": cms, "flops_effective": fl, "TFLOP/s": fl / (cms * 1e-3) / 1e12,
+                               "frac": fl / (cms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "peak": PEAK_F32_MFMA_TFLOPS,
+                               "peak_effective": peff, "frac_effective": fl / (cms * 1e-3) / 1e12 / peff,
+                               "kernels": picks,
+                               "timing": "HIP events around the four forward gather-GEMM launches, %d extra calls" % n_inst}}
+    eng._ws.pop(B, None)                       # ~4 GB of buffers nobody needs afterwards
+    torch.cuda.empty_cache()
+    return out
+
+
+def traj_bench(device, steps=30, warmup=10):
+    """BASELINE config 5's per-GPU shape: trajectory_model.yaml with train_seq_len 64, 512 sequences per GPU (4096 / 8
+    ranks), TrajectoryModel forward + both losses + backward + Adam (trajectory_pred_model.py:206-303) under hipGraph
+    replay, synthetic batches resident in HBM."""
+    from hm_vae_amd.trainer_motion_vae import Trainer
+    from hm_vae_amd.utils_common import get_config
+    from hm_vae_amd.utils_motion_vae import SyntheticMotionLoader
+    from hm_vae_amd.graph_step import GraphedStep
+    cfg = get_config(os.path.join(ROOT, "configs", "trajectory_model.yaml"))
+    B, T = 512, 64
+    cfg["batch_size"], cfg["train_seq_len"] = B, T
+    tr = Trainer(cfg)
+    tr.cuda()
+    batches = list(SyntheticMotionLoader(B, T, device, 4, 0, with_positions=True))
+    gs = GraphedStep(tr, cfg, batches[0], 0, use_graph=True)
+    for i in range(warmup):
+        gs.set_batch(batches[i % 4])
+        gs.run(lag=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        gs.set_batch(batches[i % 4])
+        gs.run(lag=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    eng = tr.model.engine(T)
+    tf = 3.0 * eng.flops_per_seq * B / dt / 1e12
+    out = {"workload": "trajectory_model.yaml, train_seq_len 64, batch 512 per GPU (config 5 = 8 x 512), fwd+bwd+Adam, "
+                       "hipGraph replay", "value": B / dt, "unit": "sequences/s", "ms_per_step": dt * 1e3, "steps": steps,
+           "conv_flops_per_step_effective": 3.0 * eng.flops_per_seq * B, "achieved_TFLOP/s": tf,
+           "peak": PEAK_F32_MFMA_TFLOPS, "frac": tf / PEAK_F32_MFMA_TFLOPS, "loss_total": float(gs.last_losses()[0])}
+    del gs, tr
+    torch.cuda.empty_cache()
+    return out
 
 
 def _host_cores():
@@ -338,12 +454,36 @@ def cpu_baseline(cfg, budget_s=28.0):
             "host": {"usable_cpus": usable, "physical_cores": phys, "logical_cpus": os.cpu_count()}}
 
 
+def kfd_gpu_count():
+    """GPUs of this node as the kernel driver lists them (/sys/class/kfd/kfd/topology/nodes/*/properties: a node with
+    simd_count > 0 is a GPU, the others are CPUs) -- no HIP call, nothing initialised: the launcher parent must stay a
+    process that has never touched the GPU.  None when the topology is not readable (the ranks then report for themselves:
+    a rank without a device fails in ddp.init_from_env / require_gpu and the launcher relays its exit code)."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    try:
+        for path in nodes:
+            for line in open(path):
+                f = line.split()
+                if len(f) == 2 and f[0] == "simd_count" and int(f[1]) > 0:
+                    n += 1
+    except (OSError, ValueError):
+        return None
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))
+    if vis is not None and vis.strip() != "":
+        n = min(n, len([v for v in vis.split(",") if v.strip() != ""]))
+    return n
+
+
 def self_launch(n):
     """Re-run this command line as N ranks of torch.distributed.run on 127.0.0.1 (a free port); returns its exit code."""
     import socket
     import subprocess
-    n_dev = torch.cuda.device_count()            # counting devices does not initialise the GPU
-    if n_dev < n and os.environ.get("HMVAE_SINGLE_DEVICE", "0") != "1":
+    n_dev = kfd_gpu_count()
+    if n_dev is not None and n_dev < n and os.environ.get("HMVAE_SINGLE_DEVICE", "0") != "1":
         sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s)\n" % (n, n_dev))
         return 2
     sock = socket.socket()
@@ -373,6 +513,9 @@ def main():
                     help="1: block on every step's loss read-back (like the reference's .item() calls); 0: the read-back "
                          "lags one step (pinned buffer + event), so the host queues step n+1 while step n runs")
     ap.add_argument("--no-phase1", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-4 sampling and config-5 trajectory lines")
+    ap.add_argument("--only", type=str, default="", choices=("", "sampling", "traj"),
+                    help="profiling aid: run only that extra section (N = 1) and print its object")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -400,8 +543,14 @@ def main():
     torch.cuda.set_device(device)
     cfg = get_config(args.config)
     torch.manual_seed(1234)
+    if args.only == "traj":
+        print(json.dumps({"traj": traj_bench(device, steps=args.steps, warmup=args.warmup)}))
+        return 0
     tr = Trainer(cfg)
     tr.cuda()
+    if args.only == "sampling":
+        print(json.dumps({"sampling": sampling_bench(tr, cfg, device, iters=args.steps)}))
+        return 0
     ddp.broadcast_parameters([p for p in tr.model.parameters() if p.requires_grad])
     T = cfg["train_seq_len"]
     B = args.batch
@@ -430,6 +579,10 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
+    # "shipped": every launch shape of the timed step came from hm_vae_amd/assets/tune_mi355x.json (choices made inside the
+    # step, keyed by problem shape and batch); "fresh": some were timed alone in this process (4-6 % slower steps)
+    from hm_vae_amd import ops as _ops
+    tuned_state = _ops.tune_state()
 
     out = {"metric": "train sequences/sec (len-64, 24-joint, TwoHierSAVAE fwd+bwd+Adam)", "value": value,
            "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -439,6 +592,7 @@ def main():
                       "len64_no_aug_hm_vae.yaml, batch %d per GPU, phase 1" % B,
                       "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world,
                       "launch": "hipGraph replay" if args.graph else "eager",
+                      "tuned": tuned_state,
                       "loss_readback": "every step, lagging one step (non-blocking)" if lag else "every step, blocking"},
            "loss_total": float(step.last_losses()[0]) if lag else float(losses[0])}
 
@@ -495,8 +649,16 @@ def main():
         # fp32 and bf16 issued flops do not add up to one rate: with both gather kernels in the step the family-level
         # issued rate is left out and per_entry_point carries one per pipe
         mixed = "hmvae_gather_gemm_v4" in timer.per_kernel and "hmvae_gather_gemm_v2" in timer.per_kernel
+        peff = effective_peak(timer.pipe_ms[label])
         out["roofline"] = {"kernel": label, "bound": "mfma", "achieved": tfl, "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": tfl / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                           "unit": "TFLOP/s", "frac": tfl / PEAK_F32_MFMA_TFLOPS,
+                           "peak_effective": peff, "frac_effective": tfl / peff,
+                           "peak_effective_note": "time-weighted over the family's launches: %.1f TFLOP/s fp32-equivalent for "
+                                                  "launches on the bf16 pipe (three planes, six MFMAs per block: 2516.6 / 6), "
+                                                  "157.3 for fp32-MFMA launches; `frac` stays against 157.3 (SURVEY 8(d)), so "
+                                                  "a frac above 1 would not mean skipped work" % PEAK_BF16X3_TFLOPS,
+                           "ms_by_pipe_per_step": {k: v / n_inst for k, v in timer.pipe_ms[label].items()},
+                           "traffic": traffic,
                            "traffic_unit": "HBM-side bytes per launch (PMC)", "traffic_source": tsrc,
                            "launches_per_step": cnt // n_inst, "avg_launch_us": ms / cnt * 1e3,
                            "timing": "HIP events on the launch stream around each C-ABI launch call of the family, %d extra "
@@ -524,6 +686,8 @@ def main():
                                                "frac": v[1] / (v[0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                                "issued_TFLOP/s": (None if (mixed and k.startswith("gather")) else
                                                                   v[3] / (v[0] * 1e-3) / 1e12),
+                                               "peak_effective": effective_peak(timer.pipe_ms[k]),
+                                               "frac_effective": v[1] / (v[0] * 1e-3) / 1e12 / effective_peak(timer.pipe_ms[k]),
                                                "launches_per_step": v[2] // n_inst}
                                            for k, v in agg.items()}}
         conv_flops_step = 3.0 * eng.flops_per_seq * B
@@ -532,6 +696,9 @@ def main():
                                          "frac": conv_flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
     if rank == 0 and world == 1 and not args.no_fk:
         out["fk_roofline"] = fk_microbench(device)
+    if rank == 0 and world == 1 and not args.no_extra:
+        out["sampling"] = sampling_bench(tr, cfg, device)
+        out["traj"] = traj_bench(device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0:

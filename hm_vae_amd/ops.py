@@ -105,7 +105,18 @@ def _tune_cache_get(key):
     return hit if hit is not None else _tune_default_get(key)
 
 
+_tune_fresh = []          # keys this process had to TIME (no shipped default, cache entry or memo hit): see tune_state()
+
+
+def tune_state():
+    """"shipped": every launch shape chosen so far came from the shipped in-step choices (assets/tune_mi355x.json) or the
+    HMVAE_TUNE_CACHE file; "fresh": at least one problem was timed alone in this process (bench.py reports it as config.tuned:
+    numbers from freshly timed shapes run 4-6 % behind the in-step choices)."""
+    return "fresh" if _tune_fresh else "shipped"
+
+
 def _tune_cache_put(key, val):
+    _tune_fresh.append(key)
     if TUNE_MEMO:
         _tune_memo[key] = list(val)
     if TUNE_CACHE is None:
@@ -142,6 +153,7 @@ class _Side:
                              bias_rows2)
         self._last_dense = None
         self._tuned_v4 = {}
+        self._tuning = False                  # a new batch size is being tuned: the fp32 layout must be current (autotune)
         self._act_now = None
         self._act_tabs = {}
         self._pp_plans = {}
@@ -271,7 +283,7 @@ class _Side:
         (or nothing is tuned yet), and every v4 companion a tuned batch size launches."""
         out = []
         picks = list(self._tuned_v4.values())
-        if not picks or any(p is None for p in picks) or self.layout == 4:
+        if not picks or any(p is None for p in picks) or self.layout == 4 or self._tuning:
             out.append(self)
         for mtw in sorted(set(p[0] for p in picks if p is not None)):
             out.append(self.v4[mtw])
@@ -408,6 +420,24 @@ class _Side:
         never inside a graph capture.  HMVAE_AUTOTUNE=0 falls back to the static v2 heuristic."""
         if bp in self._tuned or self.tune is not None or not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return
+        # A batch size this side has not seen.  Once every tuned batch size picked the v4 kernel the weight packs stopped
+        # refreshing this side's own fp32 layout (pack_targets), so it may hold the weights of many steps ago: the v2 / v3
+        # launch that this batch size may end up with -- e.g. decode() / encode_batch() at the test loader's batch after
+        # training at 256 -- must not read it.  Repack it now, keep it among the pack targets while the candidates are timed,
+        # and let every live MultiPack pick up the outcome.
+        stale = (self.layout != 4 and self._last_dense is not None and bp not in self._tuned_v4
+                 and not any(t is self for t in self.pack_targets()))
+        if stale:
+            self._tuning = True
+            MultiPack(self.device).run([(self, self._last_dense)])
+        try:
+            self._autotune_new(src, dst, bp, bias, flags, slope)
+        finally:
+            if stale:
+                self._tuning = False
+                MultiPack.refresh(self)
+
+    def _autotune_new(self, src, dst, bp, bias, flags, slope):
         g = self.g
         ck = self.tune_key(bp)
         hit = _tune_cache_get(ck)

@@ -338,6 +338,7 @@ class OracleVAE:
         self.unpool_w = [unpool_matrix(p.pooling[p.L - 1 - i], p.dec_cin[i] // p.edge_num[p.L - 1 - i]).to(dtype)
                          for i in range(p.L)]
         self.params = {}
+        self.branch, self.band, self.n_ambiguous = None, 1e-5, 0          # see _leaky
         if params is not None:
             self.load(params)
 
@@ -362,6 +363,19 @@ class OracleVAE:
         return [(n, self.params[n]) for n in order]
 
     # -- encoder (seq_two_hier_sa_vae.py:142-166) --
+    def _leaky(self, pre, key):
+        """LeakyReLU(0.2).  With self.branch set (checker aid for big batches, as in OracleTrajectory.encode): the
+        derivative jumps at 0, so for an input within fp32 rounding of 0 (|x| < self.band) both sides are valid fp32
+        evaluations; there -- and only there -- the oracle follows branch[key], a bool (B,C,T) tensor "the implementation
+        under test took the positive side".  self.n_ambiguous counts those elements."""
+        x = F.leaky_relu(pre, 0.2)
+        br = None if self.branch is None else self.branch.get(key)
+        if br is not None:
+            amb = pre.detach().abs() < self.band
+            self.n_ambiguous += int(amb.sum())
+            x = torch.where(amb, torch.where(br, pre, 0.2 * pre), x)
+        return x
+
     def encode(self, x):
         p, P = self.plan, self.params
         zs, acts = [], []
@@ -369,7 +383,7 @@ class OracleVAE:
             x = skel_conv(x, P["enc.layers.%d.0.weight" % i], self.masks["enc.layers.%d.0.mask" % i],
                           P["enc.layers.%d.0.bias" % i], p.strides[i], p.pad, p.pad_mode)
             x = torch.matmul(self.pool_w[i], x)
-            x = F.leaky_relu(x, 0.2)
+            x = self._leaky(x, ("enc", i))
             acts.append(x)
             b = x.shape[0]
             k_edges = x.shape[1] // p.ch_base[i + 1]
@@ -402,7 +416,7 @@ class OracleVAE:
             x = skel_conv(x, P[ck + ".weight"], self.masks[ck + ".mask"], bias, 1,
                           p.pad, p.pad_mode)
             if i != L - 1:
-                x = F.leaky_relu(x, 0.2)
+                x = self._leaky(x, ("dec", i))
         return x
 
     # -- decode tail (seq_two_hier_sa_vae.py:436-474) --

@@ -50,6 +50,19 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def scaled_err(a, b, tol):
+    """Worst |a - b| / (tol * |b| + tol * rms(b)) over the tensor: <= 1 means every entry sits within `tol` of its own
+    magnitude plus `tol` of the tensor's RMS.  rel_err above normalises by the LARGEST entry, so a wrong block of small
+    entries in a wide-range gradient could hide behind it; this bound is relative to the typical entry."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    bound = tol * np.abs(b) + tol * np.sqrt(np.mean(b * b))
+    diff = np.abs(a - b)
+    if not diff.any():
+        return 0.0
+    return float((diff / np.maximum(bound, 1e-300)).max())
+
+
 def load_traj_cfg(T=None):
     with open(os.path.join(CONFIGS, "trajectory_model.yaml")) as f:
         cfg = yaml.safe_load(f)

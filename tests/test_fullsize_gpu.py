@@ -1,11 +1,15 @@
-"""Full-size runs (BASELINE.json configs 2 and 4) checked through size-independent properties: the CPU oracle does not
-finish these in seconds, the properties do not need it."""
+"""Full-size runs at the shapes bench.py measures (BASELINE.json configs 2, 4 and 5's per-GPU shape).
+
+Round 3: the benched configurations are pinned to the ORACLE, not only to properties -- the oracle's B = 256 step takes
+well under a second on the box's host cores (fp32; a few seconds in float64), so "does not finish in seconds" no longer
+excuses config 2.  The launch shapes these tests run are the shipped in-step choices (hm_vae_amd/assets/tune_mi355x.json),
+i.e. the very kernels behind the bench line; the tests assert that.  The older size-independent property tests follow."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import hmvae_oracle as O
-from helpers import load_cfg, offsets
+from helpers import load_cfg, load_traj_cfg, load_traj_golden, offsets, rel_err, scaled_err
 
 pytestmark = pytest.mark.gpu
 
@@ -18,6 +22,195 @@ def dev():
 
 
 EPS32 = float(np.finfo(np.float32).eps)        # 1.19e-7
+TOL = 1e-4                                     # north_star: 1e-4 relative, fp32
+
+
+def _bct(t, B, Cn, T):
+    """SoA engine buffer [Cn*T][bp] -> (B, Cn, T) host array."""
+    from hm_vae_amd import ops
+    out = torch.empty(B, Cn * T, device=t.device)
+    ops.soa_to_aos(t, out, B, 1, Cn * T, t.shape[1])
+    return out.reshape(B, Cn, T).cpu()
+
+
+def _seeded_trainer(cfg, dev):
+    from hm_vae_amd.trainer_motion_vae import Trainer
+    tr = Trainer(cfg)
+    plan = O.Plan(cfg)
+    seeded = O.name_seeded_params(plan)
+    sd = tr.model.state_dict()
+    for k, v in seeded.items():
+        sd[k] = v.clone()
+    tr.model.load_state_dict(sd)
+    tr.cuda()
+    return plan, tr, seeded
+
+
+def _device_branches(eng, w, B):
+    """Which side of every LeakyReLU the device took, from the engine's activated buffers (sign of the output = sign of the
+    input), keyed like OracleVAE._leaky: the oracle follows these ONLY where its own input is within 1e-5 of 0."""
+    p, L = eng.p, eng.p.L
+    br = {}
+    for i in range(L):
+        t = p.tsteps[i + 1]
+        br[("enc", i)] = _bct(w["A%d" % i], B, p.ch_base[i + 1] * p.edge_num[i + 1], t) > 0
+    for i in range(L - 1):
+        t = p.dec_ts[i + 1]
+        if i == L - 2:       # the per-edge concat buffer: the convolution's channels sit in front of the skip channels
+            full = _bct(w["D%d" % i], B, p.edge_num[1] * (eng.cD + eng.cH), t)
+            idx = torch.tensor([(c // eng.cD) * (eng.cD + eng.cH) + c % eng.cD for c in range(p.dec_cout[i])])
+            br[("dec", i)] = full[:, idx] > 0
+        else:
+            br[("dec", i)] = _bct(w["D%d" % i], B, p.dec_cout[i], t) > 0
+    return br
+
+
+@pytest.mark.parametrize("phase", ["p2", "p1"])
+def test_config2_benched_step_vs_oracle(dev, phase):
+    """BASELINE config 2 -- len64, B = 256 -- with the launch shapes bench.py runs (shipped tune picks: the bf16-plane
+    gather kernel on most sides, wgrad mode 2 / 3 short splits): losses, decoder output, dL/d(dec_out), the None-gradient
+    set and EVERY gradient entry against OracleVAE(float64) at 1e-4 -- max-normalised AND entry-scaled (helpers.scaled_err)
+    -- and against the fp32 oracle (the reference's own arithmetic) at 2e-4.  seq_two_hier_sa_vae.py:335-417.
+
+    1.7 M LeakyReLU inputs per layer side: a few land within fp32 rounding of 0, where the derivative is decided by
+    summation order; for |x| < 1e-5 (counted, bounded) the oracle follows the device's branch, everywhere else its own."""
+    from hm_vae_amd import ops
+    cfg = load_cfg("len64")
+    B, T = 256, cfg["train_seq_len"]
+    plan, tr, seeded = _seeded_trainer(cfg, dev)
+    batch = O.synthetic_batch(B, T, seed=11)
+    eps = O.level_eps(plan, B, seed=12)
+    it = 0 if phase == "p1" else cfg["iteration_interval"]
+    fresh0 = len(ops._tune_fresh)
+    tr.model.eps_override = eps
+    out = tr.model(batch, cfg, it)
+    eng = tr.model.engine()
+    w = eng.workspace(B)
+    bp = w["bp"]
+    # the step above ran the shipped choices: nothing was timed afresh, most sides run the bf16-plane kernel, every
+    # convolution's weight gradient the bf16-plane GEMM (hmvae_wgrad_desc.mode 2, or 3 = mode 2 on tile pairs)
+    if ops.AUTOTUNE and ops.TUNE_CACHE is None and ops.USE_V4 == "auto":
+        assert len(ops._tune_fresh) == fresh0, ops._tune_fresh[fresh0:]
+        sides = [sd for c in eng.enc_conv + eng.dec_conv for sd in (c.fwd, c.bwd) if sd is not None]
+        assert sum(1 for sd in sides if sd._tuned_v4.get(bp) is not None) >= 8
+        assert all(c.wg_mode(bp) in (2, 3) for c in eng.enc_conv + eng.dec_conv)
+    L = plan.L
+    dec = _bct(w["D%d" % (L - 1)], B, 144, T).numpy()
+    ddec = _bct(w["dD%d" % (L - 1)], B, 144, T).numpy()
+    branch = _device_branches(eng, w, B)
+    mine = {n: (None if p.grad is None else p.grad.detach().cpu().numpy()) for n, p in tr.model.named_parameters()
+            if p.requires_grad}
+    keys = ("total", "kl", "rec_6d", "rec_rot", "rec_pose")
+    for dtype, tol in ((torch.float64, TOL), (torch.float32, 2 * TOL)):
+        orc = O.OracleVAE(cfg, seeded, offsets=offsets(), dtype=dtype)
+        orc.branch = branch
+        ref = orc.train_forward(batch, it, eps)
+        assert orc.n_ambiguous < 2000, orc.n_ambiguous
+        assert rel_err([float(x) for x in out[:5]], [float(ref[k]) for k in keys]) < TOL
+        assert rel_err([float(k) for k in out[9]], [float(k) for k in ref["kl_list"]]) < TOL
+        assert rel_err(dec, ref["dec_out"].detach().numpy()) < TOL
+        assert scaled_err(dec, ref["dec_out"].detach().numpy(), tol) <= 1.0
+        assert rel_err(ddec, ref["dec_out"].grad.numpy()) < tol
+        assert scaled_err(ddec, ref["dec_out"].grad.numpy(), tol) <= 1.0
+        none = []
+        for name, p in orc.trainable():
+            if p.grad is None:
+                assert mine[name] is None, name
+                none.append(name)
+                continue
+            assert mine[name] is not None, name
+            assert rel_err(mine[name], p.grad.numpy()) < tol, (name, str(dtype))
+            assert scaled_err(mine[name], p.grad.numpy(), tol) <= 1.0, (name, str(dtype))
+        assert len(none) == (10 if phase == "p1" else 8)               # SURVEY 3.1
+    for k, m in O.oracle_masks(plan).items():
+        assert float(np.abs(mine[k.replace("mask", "weight")] * (1 - m.numpy())).max()) == 0.0
+
+
+def test_config5_shape_traj_step_vs_oracle(dev):
+    """BASELINE config 5's per-GPU shape -- TrajectoryModel, T = 64, B = 512 (4096 / 8 ranks): both losses, the predicted
+    root velocity and every gradient entry against OracleTrajectory (float64 at 1e-4, fp32 at 2e-4), the oracle following
+    the device's LeakyReLU branch only within 1e-5 of 0.  trajectory_pred_model.py:206-303."""
+    from hm_vae_amd import ops
+    from hm_vae_amd.trainer_motion_vae import Trainer
+    B, T = 512, 64
+    cfg = load_traj_cfg(T)
+    tr = Trainer(cfg)
+    plan = O.TrajPlan(cfg)
+    seeded = O.traj_name_seeded_params(plan)
+    sd = tr.model.state_dict()
+    for k, v in seeded.items():
+        sd[k] = v.clone()
+    tr.model.load_state_dict(sd)
+    tr.cuda()
+    g, _ = load_traj_golden("len40")             # (only its de-standardisation constants)
+    batch = O.synthetic_traj_batch(B, T, seed=21)
+    out = tr.model(batch, cfg, 0)
+    eng = tr.model.last_engine
+    w = eng.workspace(B)
+    branch = []
+    for i in range(plan.L):
+        rows = w["A%d" % i].shape[0]
+        branch.append(_bct(w["A%d" % i], B, rows // T, T) > 0)
+    v = torch.empty(B, T, 3, device=dev)
+    ops.soa_to_aos(w["V"], v, B, T, 3, w["bp"])
+    mine = dict(tr.model.named_parameters())
+    for dtype, tol in ((torch.float64, TOL), (torch.float32, 2 * TOL)):
+        orc = O.OracleTrajectory(cfg, seeded, g["mean_root"], g["std_root"], dtype=dtype)
+        ref = orc.train_forward(batch, branch=branch)
+        assert orc.n_ambiguous < 2000, orc.n_ambiguous
+        assert rel_err([float(out[0]), float(out[6]), float(out[8])],
+                       [float(ref["total"]), float(ref["rec_root_v"]), float(ref["rec_root_trans"])]) < TOL
+        assert rel_err(v.cpu().numpy(), ref["root_v_out"].detach().numpy()) < TOL
+        for name, p in orc.trainable():
+            assert rel_err(mine[name].grad.cpu().numpy(), p.grad.numpy()) < tol, (name, str(dtype))
+            assert scaled_err(mine[name].grad.cpu().numpy(), p.grad.numpy(), tol) <= 1.0, (name, str(dtype))
+
+
+def test_config4_sampling_end_to_end_vs_oracle(dev):
+    """BASELINE config 4 end to end: z-list randn (4096,14,12), (4096,9,24), (4096,7,24) x 2 -> _decode -> (6D, R, joint
+    positions) at B = 4096 (64 column blocks through the decoder's four forward convolutions), the first 64 and 64 random
+    sequences against the oracle's decoder + lift + FK.  seq_two_hier_sa_vae.py:609-610,629-632 -> :436-474.
+
+    The decoder output (= the 6D result) is held to 1e-4 outright.  R = lift(6D) amplifies a 6D difference by
+    1 / sin(angle(a, b)) (my_tools.py:19-39, Gram-Schmidt), so R and the positions are held to 1e-4 against the oracle
+    where every joint up the chain has sin > 0.05 (the vast majority, counted), and everywhere to the oracle's lift + FK
+    evaluated on the DEVICE's 6D / R with the conditioning-scaled bound of the config-4 property test below."""
+    cfg = load_cfg("len64")
+    plan, tr, seeded = _seeded_trainer(cfg, dev)
+    B, T = 4096, cfg["train_seq_len"]
+    gen = torch.Generator().manual_seed(404)
+    zl = [torch.randn(B, plan.edge_num[i + 1], plan.lat_dim[i], generator=gen) for i in range(plan.L)]
+    ret = tr.model._decode(zl)
+    assert len(ret) == 7 and all(r is None for r in ret[3:])
+    c6, R, pos = ret[:3]
+    assert tuple(c6.shape) == (B, T, 24, 6) and tuple(R.shape) == (B, T, 24, 3, 3) and tuple(pos.shape) == (B, T, 24, 3)
+    pick = torch.cat([torch.arange(64), 64 + torch.randperm(B - 64, generator=gen)[:64]])
+    orc = O.OracleVAE(cfg, seeded, offsets=offsets())
+    with torch.no_grad():
+        c6_o, R_o, pos_o, _ = orc.decode([z[pick] for z in zl])
+    c6_d, R_d, pos_d = c6[pick.to(dev)].cpu(), R[pick.to(dev)].cpu(), pos[pick.to(dev)].cpu()
+    assert rel_err(c6_d.numpy(), c6_o.numpy()) < TOL
+    assert scaled_err(c6_d.numpy(), c6_o.numpy(), TOL) <= 1.0
+    sin = _lift_conditioning(c6_d).reshape(-1, 24)                            # (128*T, 24)
+    par = O.SMPL24_PARENTS
+    chain_ok = [None] * 24
+    for j in range(24):
+        chain_ok[j] = (sin[:, j] > 0.05) if par[j] < 0 else (chain_ok[par[j]] & (sin[:, j] > 0.05))
+    ok_j = sin > 0.05
+    dR = (R_d.reshape(-1, 24, 9) - R_o.reshape(-1, 24, 9)).abs().amax(dim=2)
+    assert float(ok_j.float().mean()) > 0.9
+    assert float(dR[ok_j].max()) < TOL
+    dP = (pos_d.reshape(-1, 24, 3) - pos_o.reshape(-1, 24, 3)).abs().amax(dim=2)
+    ok_p = torch.stack([chain_ok[max(par[j], 0)] for j in range(24)], dim=1)   # a position depends on its ANCESTORS' rotations
+    assert float(ok_p.float().mean()) > 0.5
+    assert float(dP[ok_p].max()) < TOL * float(pos_o.abs().max())
+    # every joint, conditioned or not: the device's R is the oracle's lift of the device's 6D, its positions the oracle's FK
+    R_l = O.rot6d_to_matrix(c6_d.reshape(-1, 24, 6))
+    bound = (2e-6 + 8.0 * EPS32 / sin.reshape(-1).double())
+    dRl = (R_d.reshape(-1, 3, 3) - R_l.reshape(-1, 3, 3)).abs().amax(dim=(1, 2)).double()
+    assert bool((dRl <= bound).all()), float((dRl / bound).max())
+    P_l = O.fk_positions(R_d.reshape(-1, 24, 3, 3), par, torch.from_numpy(offsets()))
+    assert float((pos_d.reshape(-1, 24, 3) - P_l).abs().max()) < 1e-5
 
 
 def _lift_conditioning(c6):

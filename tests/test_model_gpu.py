@@ -196,6 +196,49 @@ def test_ragged_batch_vs_oracle(dev):
         assert rel_err(mine[name].grad.cpu().numpy(), p.grad.numpy()) < 2 * TOL, name
 
 
+def test_new_batch_size_after_v4_picks_reads_current_weights(dev, monkeypatch):
+    """Round-2 advisor finding: once every tuned batch size of a side runs the v4 kernel, the weight packs stop refreshing
+    the side's own fp32 layout; a NEW batch size that ends up on the v2 / v3 kernels (train at 256, then test() / gen_seq /
+    _decode with the test loader's batch) then launched them on the layout as last packed -- old weights, silently, for
+    the first forward.  Train two steps at B = 70 with v4 forced wherever it applies, move the weights, then run a
+    validation forward and _decode at B = 3 with v4 unavailable: both must see the CURRENT weights (oracle, 1e-4)."""
+    from hm_vae_amd import ops
+    monkeypatch.setattr(ops, "USE_V4", "1")
+    cfg, plan, tr, seeded = make_trainer("len64", dev)
+    B = 70
+    batch = O.synthetic_batch(B, cfg["train_seq_len"], seed=31)
+    tr.model.eps_override = O.level_eps(plan, B, seed=32)
+    for s in range(2):
+        tr.gen_update(batch, cfg, s, False)
+    eng = tr.model.engine()
+    bp = ops.pad_batch(B)
+    sides = [sd for c in eng.enc_conv + eng.dec_conv for sd in (c.fwd, c.bwd) if sd is not None]
+    gone = [sd for sd in sides if not any(t is sd for t in sd.pack_targets())]
+    assert len(gone) >= 8                                   # these sides' fp32 layouts are no longer packed
+    with torch.no_grad():
+        for n, p in tr.model.named_parameters():
+            if p.requires_grad and p.dim() == 3:
+                p.mul_(1.25)                                # (masked-out entries are poison either way)
+    monkeypatch.setattr(ops, "USE_V4", "0")                 # the new batch size gets no v4 pick
+    now = {k: v.detach().cpu() for k, v in tr.model.state_dict().items()}
+    orc = O.OracleVAE(cfg, now, offsets=offsets())
+    b3 = O.synthetic_batch(3, cfg["train_seq_len"], seed=33)
+    e3 = O.level_eps(plan, 3, seed=34)
+    ref = orc.train_forward(b3, 0, e3, backward=False)
+    tr.model.eps_override = e3
+    ret = tr.gen_update(b3, cfg, 0, False, validation_flag=True)
+    assert rel_err(np.array(ret[:5]), [float(ref[k]) for k in ("total", "kl", "rec_6d", "rec_rot", "rec_pose")]) < TOL
+    assert all(sd._tuned_v4.get(64, "x") is None for sd in gone)
+    assert all(any(t is sd for t in sd.pack_targets()) for sd in gone)      # and they are packed again from now on
+    gen = torch.Generator().manual_seed(35)
+    zl = [torch.randn(5, plan.edge_num[i + 1], plan.lat_dim[i], generator=gen) for i in range(plan.L)]
+    with torch.no_grad():
+        c6_o, R_o, pos_o, _ = orc.decode(zl)
+    c6, R, pos = tr.model._decode(zl)[:3]
+    assert rel_err(c6.cpu().numpy(), c6_o.numpy()) < TOL
+    assert rel_err(pos.cpu().numpy(), pos_o.numpy()) < TOL
+
+
 def test_module_composition_matches_oracle(dev):
     """Encoder / Decoder called as ordinary differentiable modules (not through the fused engine)."""
     cfg, plan, tr, seeded = make_trainer("len8", dev)
