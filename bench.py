@@ -454,13 +454,13 @@ def cpu_baseline(cfg, budget_s=28.0):
             "host": {"usable_cpus": usable, "physical_cores": phys, "logical_cpus": os.cpu_count()}}
 
 
-def kfd_gpu_count():
+def kfd_gpu_count(root="/sys/class/kfd/kfd/topology/nodes"):
     """GPUs of this node as the kernel driver lists them (/sys/class/kfd/kfd/topology/nodes/*/properties: a node with
     simd_count > 0 is a GPU, the others are CPUs) -- no HIP call, nothing initialised: the launcher parent must stay a
     process that has never touched the GPU.  None when the topology is not readable (the ranks then report for themselves:
     a rank without a device fails in ddp.init_from_env / require_gpu and the launcher relays its exit code)."""
     import glob
-    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    nodes = glob.glob(os.path.join(root, "*", "properties"))
     if not nodes:
         return None
     n = 0

@@ -285,6 +285,23 @@ class VaeEngine(_StepBase):
             tot += 2 * op.useful_macs_per_col
         return tot
 
+    def noise_state_dict(self):
+        """Seed and launch counter of the in-kernel noise generator (hmvae_randn), or None before its first use: saved
+        with the optimiser checkpoint so that a resumed run continues the noise stream instead of replaying it from 0."""
+        if self._noise_state is None:
+            return None
+        return {"seed": int(self._noise_seed), "state": [int(v) for v in self._noise_state.tolist()]}
+
+    def load_noise_state(self, d):
+        if not d:
+            return
+        self._noise_seed = int(d["seed"]) & 0xFFFFFFFFFFFFFFFF
+        st = torch.tensor([int(v) for v in d["state"]], dtype=torch.int64, device=self.device)
+        if self._noise_state is None:
+            self._noise_state = st
+        else:
+            self._noise_state.copy_(st)          # (a captured graph holds this tensor's address)
+
     def workspace(self, B):
         if B in self._ws:
             return self._ws[B]

@@ -27,6 +27,12 @@ import warnings as _warnings
 
 _RETIRED = []
 MAX_RETIRED = 64
+# Parked graphs are bounded: per-item capturers stop capturing at MAX_RETIRED (may_capture), and whatever still retires
+# graphs beyond that (a trainer re-built hundreds of times in one process) has the OLDEST ones destroyed once TRIM_AT are
+# parked -- deterministic, oldest first, after a device synchronisation, down to MAX_RETIRED.  Destroying is the unsafe
+# operation on the 7.0.x runtime (about one crash per 300 destroys in tools/repro), which is why the threshold sits far
+# above anything training, the refinement loop or the test suite reach; on runtimes >= 7.2 nothing is ever parked.
+TRIM_AT = int(_os.environ.get("HMVAE_GRAPH_TRIM_AT", "256"))
 _warned = [False]
 
 
@@ -65,6 +71,9 @@ def retire(*graphs):
         return
     if parking():
         _RETIRED.extend(graphs)
+        if len(_RETIRED) > TRIM_AT:
+            torch.cuda.synchronize()
+            del _RETIRED[:len(_RETIRED) - MAX_RETIRED]          # oldest first
     else:
         torch.cuda.synchronize()            # nothing of the graph is in flight when its last reference goes
 

@@ -106,6 +106,12 @@ class Trainer(nn.Module):
         state_dict = torch.load(os.path.join(checkpoint_dir, 'optimizer.pt'), map_location="cpu", weights_only=True)
         self.gen_opt.load_state_dict(state_dict['gen'])
         self.gen_scheduler = get_scheduler(self.gen_opt, hp, iterations)
+        # (not in the reference's file: where the in-kernel noise stream of the reparametrisation stood, so that the resumed
+        # run draws fresh noise instead of replaying the stream from its start; the reference's loader ignores extra keys)
+        if state_dict.get('noise') and hasattr(this_model, 'engine') and next(this_model.parameters()).is_cuda:
+            eng = this_model.engine()
+            if hasattr(eng, 'load_noise_state'):
+                eng.load_noise_state(state_dict['noise'])
         print('Resume from iteration %d' % iterations)
         return iterations
 
@@ -116,7 +122,12 @@ class Trainer(nn.Module):
         gen_name = os.path.join(snapshot_dir, 'gen_%08d.pt' % (iterations + 1))
         opt_name = os.path.join(snapshot_dir, 'optimizer.pt')
         torch.save({'state_dict': this_model.state_dict()}, gen_name, _use_new_zipfile_serialization=False)
-        torch.save({'gen': self.gen_opt.state_dict()}, opt_name, _use_new_zipfile_serialization=False)
+        opt_state = {'gen': self.gen_opt.state_dict()}
+        eng = getattr(this_model, '_engine', None)
+        noise = eng.noise_state_dict() if (eng is not None and hasattr(eng, 'noise_state_dict')) else None
+        if noise is not None:
+            opt_state['noise'] = noise
+        torch.save(opt_state, opt_name, _use_new_zipfile_serialization=False)
 
     def load_ckpt(self, ckpt_name):
         this_model = self._this_model()

@@ -252,3 +252,19 @@ def test_single_process_helpers_are_noops():
     t = torch.arange(4.0)
     assert ddp.all_reduce_mean_(t) is t and torch.equal(t, torch.arange(4.0))
     ddp.broadcast_parameters([torch.zeros(3)])
+
+
+def test_launcher_counts_gpus_from_kfd_topology(tmp_path, monkeypatch):
+    """bench.py's launcher parent counts GPUs from the kernel driver's topology files (simd_count > 0), without any HIP
+    call: two CPU nodes + three GPU nodes -> 3; HIP_VISIBLE_DEVICES narrows it; no topology -> None (no check)."""
+    import bench
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simd == 0 else 0, simd))
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    assert bench.kfd_gpu_count(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.kfd_gpu_count(str(tmp_path)) == 2
+    assert bench.kfd_gpu_count(str(tmp_path / "nothing_here")) is None

@@ -228,8 +228,9 @@ def test_new_batch_size_after_v4_picks_reads_current_weights(dev, monkeypatch):
     tr.model.eps_override = e3
     ret = tr.gen_update(b3, cfg, 0, False, validation_flag=True)
     assert rel_err(np.array(ret[:5]), [float(ref[k]) for k in ("total", "kl", "rec_6d", "rec_rot", "rec_pose")]) < TOL
-    assert all(sd._tuned_v4.get(64, "x") is None for sd in gone)
-    assert all(any(t is sd for t in sd.pack_targets()) for sd in gone)      # and they are packed again from now on
+    seen = [sd for sd in gone if 64 in sd._tuned_v4]                        # the forward sides: they met the new batch size
+    assert len(seen) >= 4 and all(sd._tuned_v4[64] is None for sd in seen)
+    assert all(any(t is sd for t in sd.pack_targets()) for sd in seen)      # and they are packed again from now on
     gen = torch.Generator().manual_seed(35)
     zl = [torch.randn(5, plan.edge_num[i + 1], plan.lat_dim[i], generator=gen) for i in range(plan.L)]
     with torch.no_grad():
@@ -291,6 +292,30 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     opt = torch.load(str(tmp_path / "optimizer.pt"), map_location="cpu", weights_only=True)["gen"]
     assert len(opt["param_groups"][0]["params"]) == 30
     assert len(opt["state"]) == 20          # 10 of the 30 tensors have no gradient in phase 1
+
+
+def test_checkpoint_carries_the_noise_stream(dev, tmp_path):
+    """The reparametrisation's noise comes from hmvae_randn (seed + device-side launch counter).  A resumed run must go on
+    where the stream stood -- not replay it from launch 0: the counter and seed travel in optimizer.pt beside 'gen' (the
+    reference's loader reads only 'gen')."""
+    g, meta = load_model_golden("len8")
+    cfg, plan, tr, seeded = make_trainer("len8", dev)
+    batch = golden_batch(g)
+    torch.manual_seed(4242)
+    for s_ in range(3):
+        tr.gen_update(batch, cfg, s_, False)
+    st = tr.model.engine().noise_state_dict()
+    assert st is not None and st["state"][0] == 3                      # three launches so far
+    tr.save(str(tmp_path), 2, False)
+    nxt = tr.gen_update(batch, cfg, 3, False)
+    opt = torch.load(str(tmp_path / "optimizer.pt"), map_location="cpu", weights_only=True)
+    assert opt["noise"] == st and set(opt.keys()) == {"gen", "noise"}
+    torch.manual_seed(999)                                             # a different process seed: the stream's own seed wins
+    cfg2, plan2, tr2, _ = make_trainer("len8", dev)
+    it = tr2.resume(str(tmp_path), cfg2, False)
+    assert tr2.model.engine().noise_state_dict() == st
+    r2 = tr2.gen_update(batch, cfg2, it, False)
+    assert rel_err(np.array(r2), np.array(nxt)) < 1e-6                 # same weights, same Adam state, same noise
 
 
 def test_train_cli_runs(dev, tmp_path):
@@ -400,6 +425,37 @@ def test_bench_two_rank_launch_rehearsal(dev, tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["scaling"] == "weak"
     assert out["value"] > 0 and np.isfinite(out["loss_total"]) and "roofline" not in out
+
+
+def test_bench_self_launch_two_ranks(dev, tmp_path):
+    """`python bench.py --gpus 2` run PLAINLY (no WORLD_SIZE in the environment): what the driver's scaling command hits.
+    bench.py must become the launcher itself -- two ranks through torch.distributed.run on 127.0.0.1, started before
+    anything touches the GPU -- and relay the exit code.  Rehearsed on one GPU (gloo, both ranks on cuda:0)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HMVAE_DIST_BACKEND="gloo", HMVAE_SINGLE_DEVICE="1", HMVAE_TUNE_CACHE=str(tmp_path / "tune.json"))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "64"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["value"] > 0
+    assert out["config"]["tuned"] in ("shipped", "fresh")
+    # a launch whose world size differs from --gpus is exit code 2, never a one-GPU line printed as if it were the request
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env1)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # ... and asking for more GPUs than the node has (no rehearsal switch) fails in the launcher, before any rank starts
+    env3 = {k: v for k, v in env.items() if k != "HMVAE_SINGLE_DEVICE"}
+    import bench
+    if bench.kfd_gpu_count() is not None and bench.kfd_gpu_count() < 3:
+        r = subprocess.run(cmd[:2] + ["--gpus", "3"] + cmd[4:], capture_output=True, text=True, timeout=600, env=env3)
+        assert r.returncode == 2 and "this node shows" in r.stderr
 
 
 def test_graph_replay_across_the_phase_switch(dev):
