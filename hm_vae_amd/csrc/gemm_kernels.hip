@@ -16,6 +16,7 @@
 #include "pack_taps_inl.h"
 #include <type_traits>
 #include "hmvae.h"
+#include "wreduce_inl.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -554,39 +555,18 @@ __device__ __forceinline__ void wreduce_body(const hmvae_wreduce_desc& d, int bl
             }
             sums[i] = s0 + s1;
         }
+        const WreduceColR wc = wreduce_col_resolve(d, tile, col);
+        if (!wc.live) continue;
         const int g = d.tile_g[tile];
-        const int gc = d.tile_col0[tile] + col;
-        if (gc >= d.g_ncols[g]) continue;
-        const int c = gc / d.kt;
-        const int tap = gc - c * d.kt;
-        const int cid = d.chan_id[d.g_choff[g] + c];
-        if (cid < 0) continue;
-        const unsigned char* okp = d.pair_ok + d.g_okoff[g] + c;
-        const int ok_stride = d.g_nc4[g] * 4;
-        float* ocol = d.dense + (size_t)cid * d.chan_stride + tap;
+        int rid[4];
+        unsigned bits[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = piece * 16 + r0 + 4 * i;
-            const int rid = d.row_id[g * rows + row];
-            if (rid < 0 || !okp[row * ok_stride]) continue;
-            float s = sums[i];
-            if (d.child_tab == nullptr) {
-                float* o = ocol + (size_t)rid * d.row_stride;
-                if (d.accumulate) s += *o;
-                *o = s;
-            } else {                                   // one computed gradient, several dense (row, channel) owners
-                const unsigned bits = okp[row * ok_stride];
-                if (d.child_scale) s *= d.child_scale[d.child_side ? rid : cid];
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci) {
-                    if (!((bits >> ci) & 1u)) continue;
-                    const int dr = d.child_side ? d.child_tab[rid * 4 + ci] : rid;
-                    const int dc = d.child_side ? cid : d.child_tab[cid * 4 + ci];
-                    float* o = d.dense + (size_t)dr * d.row_stride + (size_t)dc * d.chan_stride + tap;
-                    *o = d.accumulate ? *o + s : s;
-                }
-            }
+            rid[i] = d.row_id[g * rows + row];
+            bits[i] = wc.okp[row * wc.ok_stride];
         }
+        wreduce_store_rows<4>(d, wc, rid, bits, sums);
     }
 }
 

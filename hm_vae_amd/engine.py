@@ -33,6 +33,9 @@ SHALLOW_SIDE = _os0.environ.get("HMVAE_SHALLOW_SIDE", "1") != "0"
 NOISE_HIP = _os0.environ.get("HMVAE_NOISE", "hip") != "torch"
 FUSE_BRIDGE = _os0.environ.get("HMVAE_FUSE_BRIDGE", "1") != "0"
 FUSE_LEAKY_BWD = _os0.environ.get("HMVAE_FUSE_LEAKY_BWD", "1") != "0"
+# weight-gradient launches on wide tiles (ops wg_mode 4) are issued when their segment's data-gradient chain is through
+# (measured 1.34 -> 1.47 ms at B = 256: the chain's launches leave CUs idle that the weight gradients fill; off by default)
+DEFER_WIDE = _os0.environ.get("HMVAE_DEFER_WIDE", "0") == "1"
 
 
 class VaePlan:
@@ -99,6 +102,7 @@ class _StepBase:
         # outside the capture, waited on by the capturing stream)
         self._join_all = _os.environ.get("HMVAE_JOIN_ALL", "0") == "1"
         self._pending_red, self._pending_rs = [], []
+        self._deferred = []
         self._events = {}
         self._skip_wgrad = False          # test-time optimisation of the latents alone: data gradients only
 
@@ -149,8 +153,18 @@ class _StepBase:
         self._forked.add(self._turn)
         return torch.cuda.stream(side)
 
+    def _flush_deferred(self):
+        lst, self._deferred = self._deferred, []
+        self._flushing = True
+        try:
+            for args in lst:
+                self._wgrad(*args)
+        finally:
+            self._flushing = False
+
     def _join(self):
         """The main stream waits for every side stream forked since the last join (and only those)."""
+        self._flush_deferred()
         if self.overlap and self._side is not None:
             main = torch.cuda.current_stream()
             for i in (range(self.n_side) if self._join_all else sorted(self._forked)):
@@ -161,6 +175,11 @@ class _StepBase:
         """bias: optional (src, grad_name, rows_key, base, n_out, rows_per_out, row_step) for the row-sum kernel.
         before: launches that produce `x`, issued on the same side stream first."""
         if self._skip_wgrad:
+            return
+        if DEFER_WIDE and not MULTI_REDUCE and not getattr(self, "_flushing", False) and op.wg_mode(bp) == 4:
+            # wide-tile launches (one 8-wave workgroup per CU holding 130 KB of LDS for the whole tile) starve the
+            # data-gradient chain when they run beside it: they are queued when the segment's chain is through (_flush_deferred)
+            self._deferred.append((op, dy, x, name, bp, w, bias, before))
             return
         slab = w["slabs"][id(op)]
         if not MULTI_REDUCE:
@@ -739,6 +758,7 @@ class VaeEngine(_StepBase):
                 self._join()
                 return
             if getattr(self, "_slice_hook", None) is not None:
+                self._flush_deferred()          # every launch that writes the slice must be queued
                 self._slice_hook("dec")
         self._backward_encoder(w, phase2, eps, B, bp, enc_w, enc_b, part if part in ("enc_hi", "enc_lo") else "all")
 
@@ -820,6 +840,7 @@ class VaeEngine(_StepBase):
                 self._join()
                 return
             if hook is not None:
+                self._flush_deferred()
                 hook("enc_hi")
                 self._backward_encoder_layers(w, phase2, bp, enc_w, enc_b, self.enc_cut - 1, 0)
         else:

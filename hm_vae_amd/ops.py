@@ -53,6 +53,17 @@ WGRAD_LDS = _os.environ.get("HMVAE_WGRAD_LDS", "auto")
 # significant cross terms run on the bf16 matrix pipe (csrc/wgrad_bf3.hip): fp32-grade sums at 3/8 of the fp32 MFMA issue
 # cycles.  A candidate of the autotuner unless HMVAE_WGRAD_BF3=0; HMVAE_WGRAD_LDS=2 forces it wherever it applies.
 WGRAD_BF3 = _os.environ.get("HMVAE_WGRAD_BF3", "1") != "0"
+# wide tiles of the same kernel family (up to 112 rows x 128 columns per 8-wave workgroup, wg_mode 4): a candidate of the
+# autotuner wherever an input block is read by more than 64 rows; "0" never; HMVAE_WGRAD_LDS=4 forces it where it applies
+WGRAD_WIDE = _os.environ.get("HMVAE_WGRAD_WIDE", "1")
+# Timed ALONE the wide launch wins where it applies (first decoder layer at B = 256: 93 against 116 us, last encoder layer 62
+# against 75), but in the step it is the worse neighbour: one 8-wave workgroup holds a CU's LDS (130 KB) for a whole 60-90 us
+# tile, and the data-gradient chain's gather launches cannot co-reside -- interleaved A/B of the graph step at B = 256: 1.34 ms
+# with the 48 x 64 tiles, 1.38-1.42 with wide tiles on either of the two layers, 1.47 with those launches deferred to the end
+# of their segment.  The alone-timed autotuner therefore counts the wide launch's time at WIDE_BIAS.
+WIDE_BIAS = float(_os.environ.get("HMVAE_WIDE_BIAS", "1.3"))
+_WG_FORCE = {int(t[0][1:] if t[0].startswith("t") else t[0]): (int(t[1]), int(t[2]))
+             for t in (e.split(":") for e in _os.environ.get("HMVAE_WG_FORCE", "").split(",") if e)}
 KEEP_IO = False          # set by tools/tune_in_situ.py: sides remember their last operands
 GATHER_WPOS = _os.environ.get("HMVAE_GATHER_WPOS", "1") != "0"       # let the autotuner time the position-per-wave launch shape
 # the mode-2 GEMM writes the dense gradient from its own epilogue where the reduction is not split (no slab, no reduce launch)
@@ -793,6 +804,7 @@ class MaskedGemm:
         wg_x_base, wg_dz_base = x_base, y_base
         dedupe = (comp is not None and rows_b is not None and (comp.get("cmap") is not None or comp.get("rmap") is not None)
                   and _os.environ.get("HMVAE_WGRAD_DEDUPE", "1") != "0")
+        wide_src = None                      # (rows_b, chans_b, pair_bits) of the weight-gradient grouping, for wide()
         if dedupe:
             # Copies of one coarse channel (SkeletonUnpool) see the same activations and rows averaged by SkeletonPool the
             # same output gradient: compute their weight gradients once (tiles over the merged ids) and let the reduce
@@ -800,6 +812,7 @@ class MaskedGemm:
             if comp.get("cmap") is not None:
                 rc, cc_, bits_b, ch_ = P.merge_channels_transposed(rows_b, chans_b, comp["cmap"], len(comp["src_base"]))
                 gw = P.make_wgrad_groups(rc, cc_, kt, pair_bits=lambda r, c, _b=bits_b: _b(c, r))
+                wide_src = (rc, cc_, lambda r, c, _b=bits_b: _b(c, r))
                 wg_x_base = np.zeros(len(comp["src_base"]), dtype=np.int64)
                 for c_, fl in ch_.items():
                     wg_x_base[c_] = x_base[fl[0]]              # every child holds the same rows of the conv's input
@@ -807,6 +820,7 @@ class MaskedGemm:
             else:
                 rb_, cp_, bits_r, ch_ = P.merge_rows_transposed(rows_b, chans_b, comp["rmap"])
                 gw = P.make_wgrad_groups(rb_, cp_, kt, pair_bits=lambda r, c, _b=bits_r: _b(c, r))
+                wide_src = (rb_, cp_, lambda r, c, _b=bits_r: _b(c, r))
                 wg_dz_base = dst_base                          # the gradient w.r.t. the POOLED pre-activation
                 self.wg_child = (_dev(ctab.reshape(-1), device), 1,
                                  torch.as_tensor(np.ascontiguousarray(scale, dtype=np.float32)).to(device))
@@ -815,23 +829,22 @@ class MaskedGemm:
                 self.pool_dst_base = dst_base
         elif rows_b is not None and len(rows_b) > 1 and _os.environ.get("HMVAE_WGRAD_G", "1") != "0":
             cand = P.make_wgrad_groups(rows_b, chans_b, kt)
+            wide_src = (rows_b, chans_b, None)
             t_f = sum(-(-int(nn) * kt // 64) for nn in gf.g_nch) * gf.mt * (1.0 + 0.35 / gf.mt)
             t_c = sum(-(-int(nn) * kt // 64) for nn in cand.g_nch) * cand.mt * (1.0 + 0.35 / cand.mt)
             if t_c < t_f:
                 gw = cand
-        self.wg = gw
         self.wg_pooled_dz = dedupe and comp.get("rmap") is not None      # backward_weight takes the pooled gradient
-        self.wg_tabs = dict(row_id=_dev(gw.row_id, device), chan_id=_dev(gw.chan_id, device), g_nc4=_dev(gw.g_nc4, device),
-                            g_choff=_dev(gw.g_choff, device), g_okoff=_dev(gw.g_okoff, device),
-                            pair_ok=_dev(gw.pair_ok, device))
-        chw = gw.chan_id
-        self.wg_chan_rows = _dev(np.where(chw >= 0, wg_x_base[np.maximum(chw, 0)],
-                                          wg_x_base[int(chw[chw >= 0][0])]).astype(np.int32), device)
-        tile_g, tile_col0, g_ncols = gw.wgrad_tiles()
-        self.n_tiles = len(tile_g)
-        self.tile_g, self.tile_col0, self.g_ncols = _dev(tile_g, device), _dev(tile_col0, device), _dev(g_ncols, device)
-        ri = gw.row_id
-        self.dz_rows = _dev(np.where(ri >= 0, wg_dz_base[np.maximum(ri, 0)], -1).astype(np.int32), device)
+        self._wg_std = self._wg_tables(gw, wg_x_base, wg_dz_base)
+        # the standard tiling under its historical attribute names (tests / tools read them)
+        self.wg, self.wg_tabs, self.wg_chan_rows = gw, self._wg_std.tabs, self._wg_std.chan_rows
+        self.n_tiles, self.tile_g, self.tile_col0 = self._wg_std.n_tiles, self._wg_std.tile_g, self._wg_std.tile_col0
+        self.g_ncols, self.dz_rows = self._wg_std.g_ncols, self._wg_std.dz_rows
+        # Wide tiles (wg_mode 4, csrc/wgrad_bf3.hip wgrad_bf3w_kernel): the same input-block keyed tiling cut into pieces of
+        # up to 112 rows (mt 5..7) and taken 128 columns at a time by one 8-wave workgroup per CU -- for the dense, weight-heavy
+        # layers, where a block is read by 100+ output rows.  Built on demand (wide()).
+        self._wide_args = (wide_src, wg_x_base, wg_dz_base) if wide_src is not None else None
+        self._wide = None
         self.x_ts, self.y_ts = int(x_ts), int(y_ts)
         # geometry of the position reduction for the weight gradient
         self.geom = conv_geom or dict(t_dst=len(pairs_f), t_src=len(pairs_f), stride=1, pad=0, pad_mode=_lib.PAD_REFLECT)
@@ -857,6 +870,42 @@ class MaskedGemm:
                 self.wg_transposed = True
                 self.n_tiles_t = len(tg_t)
                 self.tile_g_t, self.tile_col0_t, self.g_ncols_t = _dev(tg_t, device), _dev(tc_t, device), _dev(nc_t, device)
+
+    def _wg_tables(self, gw, wg_x_base, wg_dz_base):
+        """Device tables of one weight-gradient tiling (GroupSet `gw`): what hmvae_wgrad_desc / hmvae_wreduce_desc point at."""
+        from types import SimpleNamespace
+        device = self.device
+        t = SimpleNamespace(g=gw, pair_tab=None, fused={})
+        t.tabs = dict(row_id=_dev(gw.row_id, device), chan_id=_dev(gw.chan_id, device), g_nc4=_dev(gw.g_nc4, device),
+                      g_choff=_dev(gw.g_choff, device), g_okoff=_dev(gw.g_okoff, device), pair_ok=_dev(gw.pair_ok, device))
+        chw = gw.chan_id
+        t.chan_rows = _dev(np.where(chw >= 0, wg_x_base[np.maximum(chw, 0)],
+                                    wg_x_base[int(chw[chw >= 0][0])]).astype(np.int32), device)
+        tile_g, tile_col0, g_ncols = gw.wgrad_tiles()
+        t.n_tiles = len(tile_g)
+        t.tile_g, t.tile_col0, t.g_ncols = _dev(tile_g, device), _dev(tile_col0, device), _dev(g_ncols, device)
+        ri = gw.row_id
+        t.dz_rows = _dev(np.where(ri >= 0, wg_dz_base[np.maximum(ri, 0)], -1).astype(np.int32), device)
+        return t
+
+    def wide(self):
+        """The wide tiling's tables (see __init__), or None where it does not apply: no input block read by more than 64
+        rows, fewer than 4 positions, a single tap, the transposed orientation, or an LDS image beyond 160 KB."""
+        if self._wide is None:
+            self._wide = False
+            ok = (self._wide_args is not None and WGRAD_WIDE != "0" and WGRAD_BF3 and self.lds_eligible()
+                  and max(len(r) for r in self._wide_args[0][1]) > 64)
+            if ok:
+                (rb, cb, bits), xb, db = self._wide_args
+                mts = tuple(int(v) for v in _os.environ.get("HMVAE_WGRAD_WIDE_MT", "7,6,5").split(","))
+                gw = P.make_wgrad_groups(rb, cb, self.kt, mt_choices=mts, pair_bits=bits)
+                if self._bf3_lds(True, mt=gw.mt) is not None:
+                    self._wide = self._wg_tables(gw, xb, db)
+        return self._wide or None
+
+    def _tabs(self, bp):
+        """The tiling this batch size's weight-gradient launch runs on."""
+        return self.wide() if self.wg_mode(bp) == 4 else self._wg_std
 
     # -- passes --
     def pack(self, weight):
@@ -912,7 +961,11 @@ class MaskedGemm:
             return 2 if self.bf3_eligible() else 0
         if WGRAD_LDS == "3":
             return 3 if self.pair_eligible() else (2 if self.bf3_eligible() else 0)
+        if WGRAD_LDS == "4":
+            return 4 if self.wide() is not None else (2 if self.bf3_eligible() else 0)
         md = int(self._mode_tuned.get(bp, 0))
+        if md == 4:
+            return 4 if (self.wide() is not None and not self.persistent(bp)) else 0
         if md == 3:
             return 3 if (WGRAD_BF3 and self.pair_eligible() and not self.persistent(bp)) else 0
         return md if (md < 2 or (WGRAD_BF3 and self.bf3_eligible())) else 0
@@ -925,13 +978,13 @@ class MaskedGemm:
     def desc_mode(self, bp):
         """hmvae_wgrad_desc.mode of the launch: wg_mode 3 is mode 2 on tile pairs (desc.pair_tab)."""
         md = self.wg_mode(bp)
-        return 2 if md == 3 else md
+        return 2 if md in (3, 4) else md
 
-    def _bf3_lds(self, pair):
+    def _bf3_lds(self, pair, mt=None):
         """Mirror of bf3_geometry (csrc/wgrad_bf3.hip): LDS bytes of a mode-2 launch, or None if unsupported."""
         ge = self.geom
-        mt = self.wg.mt
-        if not self.lds_eligible() or mt > 4:
+        mt = self.wg.mt if mt is None else mt
+        if not self.lds_eligible() or mt > (7 if pair else 4):
             return None
         nch_max = (127 if pair else 63) // self.kt + 2
         W = 3 * ge["stride"] + self.kt
@@ -943,15 +996,30 @@ class MaskedGemm:
         if (nch_max * W + prows - 1) // prows > 8:
             return None
         lds = (nch_max * WT * 4 + 15) // 16 * 16 + 3 * (mt * 16 * 4 + nch_max * WP + 1) * 64
-        lds = max(lds, (8 if pair else 4) * mt * 16 * 64 * 4)
+        lds = max(lds, (8 * 16 * 64 * 4) if mt > 4 else (8 if pair else 4) * mt * 16 * 64 * 4)
+        if mt > 4 and ((nch_max * W + prows - 1) // prows > 4 or lds + 64 > 160 * 1024):
+            return None
         return lds if lds <= (160 if pair else 80) * 1024 else None
 
     def pair_eligible(self):
         """Mode 2 on pairs of neighbouring column tiles (8-wave workgroups): worth it only where pairs exist."""
         return self._bf3_lds(True) is not None and self.pair_tab()[1] < self.n_tiles
 
-    def pair_tab(self):
+    def pair_tab(self, t=None):
         """(device table [n_pairs][2], n_pairs): consecutive 64-column tiles of one row group taken two at a time."""
+        if t is not None and t is not self._wg_std:
+            if t.pair_tab is None:
+                tg, tc, _ = t.g.wgrad_tiles()
+                pairs, i = [], 0
+                while i < len(tg):
+                    if i + 1 < len(tg) and tg[i + 1] == tg[i] and tc[i + 1] == tc[i] + 64:
+                        pairs.append((i, i + 1))
+                        i += 2
+                    else:
+                        pairs.append((i, -1))
+                        i += 1
+                t.pair_tab = (_dev(np.asarray(pairs, dtype=np.int32).reshape(-1), self.device), len(pairs))
+            return t.pair_tab
         if self._pair_tab is None:
             tg, tc, _ = self.wg.wgrad_tiles()
             pairs, t = [], 0
@@ -996,7 +1064,7 @@ class MaskedGemm:
         # resident workgroups per CU by registers (VGPR + AGPR of the unified 512 per SIMD lane): mt 1 / 2 use 128 / 198,
         # mt 3 uses 268 and mt 4 333 -> one wave per SIMD (counted with rocprofv3: 838 of 1024 wave slots busy on average
         # for 1127 one-per-CU workgroups: the fifth round is 40 % empty)
-        per_cu = int(_os.environ.get("HMVAE_WG_PER_CU", "0")) or (1 if self.wg_mode(bp) == 3 else (2 if (mt <= 2 or self.wg_mode(bp) >= 1) else 1))
+        per_cu = int(_os.environ.get("HMVAE_WG_PER_CU", "0")) or (1 if self.wg_mode(bp) in (3, 4) else (2 if (mt <= 2 or self.wg_mode(bp) >= 1) else 1))
         n_workers = max(8, (n_cu * per_cu) // 8 * 8)
         segs, wseg, _, _ = P.build_stream_schedule([kc] * n_tiles, [1] * n_tiles, n_workers, min_steps=2)
         items = np.zeros((max(len(segs), 1), 4), dtype=np.int32)
@@ -1019,17 +1087,39 @@ class MaskedGemm:
         per = n_tiles * mt * 16 * 64
         n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 256
         parts_p = n_tiles + 2 * n_cu + 8              # upper bound of the persistent schedule's parts
-        return max(max(self.split_candidates(bp)) * per, parts_p * mt * 16 * 64)
+        need = max(max(self.split_candidates(bp)) * per, parts_p * mt * 16 * 64)
+        w = self.wide() if not self.wg_transposed else None
+        if w is not None:
+            need = max(need, max(self.wide_split_candidates(bp)) * w.n_tiles * w.g.mt * 16 * 64)
+        return need
+
+    def wide_split_candidates(self, bp):
+        """K splits of the wide launch worth timing: one 8-wave workgroup per CU, so about one or two rounds of the chip."""
+        w = self.wide()
+        n_units = self.pair_tab(w)[1]
+        kc = self._k_chunks(bp)
+        n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 256
+        cand = [c for c in (1, 2, 3, 4, 6, 8) if c <= max(1, kc // 8) and (c == 1 or n_units * c <= 2.2 * n_cu)]
+        return cand or [1]
 
     def wg_tune_key(self, bp):
-        return "wg5_t%d_m%d_k%d_c%d_tr%d_b%d" % (self.n_tiles_t if self.wg_transposed else self.n_tiles, self.wg.mt, self.kt,
-                                                 self._k_chunks(bp), int(self.wg_transposed), bp)
+        w = self.wide() if not self.wg_transposed else None
+        return "wg6_t%d_m%d_k%d_c%d_tr%d_w%d_b%d" % (self.n_tiles_t if self.wg_transposed else self.n_tiles, self.wg.mt, self.kt,
+                                                     self._k_chunks(bp), int(self.wg_transposed),
+                                                     0 if w is None else w.n_tiles * 8 + w.g.mt, bp)
 
     def autotune_split(self, dy, x, dw, bp, slab):
         if bp in self._split_tuned or not AUTOTUNE or torch.cuda.is_current_stream_capturing():
             return
         ck = self.wg_tune_key(bp)
         hit = _tune_cache_get(ck)
+        if hit is None:         # choices recorded before the wide tiling existed (keys without its field) still name this problem
+            hit = _tune_cache_get("wg5_t%d_m%d_k%d_c%d_tr%d_b%d" % (self.n_tiles_t if self.wg_transposed else self.n_tiles,
+                                                                  self.wg.mt, self.kt, self._k_chunks(bp),
+                                                                  int(self.wg_transposed), bp))
+        force = _WG_FORCE.get(self.n_tiles)     # experiments: HMVAE_WG_FORCE="<std tiles>:<mode>:<split>,..."
+        if force is not None and not self.wg_transposed:
+            hit = [force[1], 0, force[0]]
         if hit is not None:
             self._split_tuned[bp] = "p" if hit[0] == "p" else int(hit[0])
             self._bf_tuned[bp] = bool(hit[1]) if len(hit) > 1 else False
@@ -1052,10 +1142,12 @@ class MaskedGemm:
                 modes.append((False, 2))
                 if self.pair_eligible():
                     modes.append((False, 3))
+                if self.wide() is not None:
+                    modes.append((False, 4))
         for bf, md in modes:
             self._bf_tuned[bp] = bf
             self._mode_tuned[bp] = md
-            for c in cands:
+            for c in ([c for c in self.wide_split_candidates(bp) if c in cands] if md == 4 else cands):
                 self._split_tuned[bp] = c
 
                 def once():
@@ -1063,7 +1155,7 @@ class MaskedGemm:
                         return
                     r = self.reduce_desc(slab, scratch, bp, False)
                     _lib.check(_lib.load().hmvae_wgrad_reduce(C.byref(r), _lib.stream()), "wgrad_reduce")
-                t = self.fwd._time(once) * (LDS_BIAS if md == 1 else 1.0)
+                t = self.fwd._time(once) * (LDS_BIAS if md == 1 else (WIDE_BIAS if md == 4 else 1.0))
                 if best is None or t < best[0]:
                     best = (t, c, bf, md)
         self._split_tuned[bp] = best[1]
@@ -1080,11 +1172,11 @@ class MaskedGemm:
 
     def fusable(self, bp):
         """The launch can write the dense gradient from its epilogue (hmvae_wgrad_desc.fused_reduce)."""
-        return FUSE_WREDUCE and self.wg_mode(bp) in (2, 3) and self.n_split(bp) == 1 and not self.persistent(bp)
+        return FUSE_WREDUCE and self.wg_mode(bp) in (2, 3, 4) and self.n_split(bp) == 1 and not self.persistent(bp)
 
     def _fused_desc(self, slab, dw, bp, accumulate):
         """Device copy of the reduce descriptor for (slab, dw): made once per pointer set, outside any stream capture."""
-        key = (slab.data_ptr(), dw.data_ptr(), int(bp), bool(accumulate))
+        key = (slab.data_ptr(), dw.data_ptr(), int(bp), bool(accumulate), self.wg_mode(bp) == 4)
         t = self._fused.get(key)
         if t is None:
             if torch.cuda.is_current_stream_capturing():
@@ -1104,11 +1196,12 @@ class MaskedGemm:
                                     _lib.ptr(self.g_ncols_t), _lib.ptr(b.g_choff), _lib.ptr(b.chan_id), _lib.ptr(b.row_id),
                                     _lib.ptr(b.g_nc4), _lib.ptr(b.g_okoff), _lib.ptr(b.pair_ok), self.n_tiles_t, g.mt, g.kt,
                                     ns, kt, n_chan * kt, 1 if accumulate else 0, None, None, 0, 0, *self._wg_parts(bp))
-        g, tb = self.wg, self.wg_tabs
-        return _lib.WreduceDesc(_lib.ptr(slab), _lib.ptr(dw), _lib.ptr(self.tile_g), _lib.ptr(self.tile_col0),
-                                _lib.ptr(self.g_ncols), _lib.ptr(tb["g_choff"]), _lib.ptr(tb["chan_id"]),
+        t = self._tabs(bp)
+        g, tb = t.g, t.tabs
+        return _lib.WreduceDesc(_lib.ptr(slab), _lib.ptr(dw), _lib.ptr(t.tile_g), _lib.ptr(t.tile_col0),
+                                _lib.ptr(t.g_ncols), _lib.ptr(tb["g_choff"]), _lib.ptr(tb["chan_id"]),
                                 _lib.ptr(tb["row_id"]), _lib.ptr(tb["g_nc4"]), _lib.ptr(tb["g_okoff"]),
-                                _lib.ptr(tb["pair_ok"]), self.n_tiles, g.mt, g.kt, ns, n_chan * kt, kt,
+                                _lib.ptr(tb["pair_ok"]), t.n_tiles, g.mt, g.kt, ns, n_chan * kt, kt,
                                 1 if accumulate else 0,
                                 None if self.wg_child is None else _lib.ptr(self.wg_child[0]),
                                 None if self.wg_child is None or self.wg_child[2] is None else _lib.ptr(self.wg_child[2]),
@@ -1130,14 +1223,15 @@ class MaskedGemm:
             return False
         lib = _lib.load()
         fused = self._fused_desc(slab, dw, bp, accumulate) if (dw is not None and self.fusable(bp)) else None
-        g = self.wg
-        tb = self.wg_tabs
+        t = self._tabs(bp)
+        g = t.g
+        tb = t.tabs
         ns = self.n_split(bp)
-        assert slab.numel() >= ns * self.n_tiles * g.mt * 16 * 64
+        assert slab.numel() >= ns * t.n_tiles * g.mt * 16 * 64
         ge = self.geom
-        d = _lib.WgradDesc(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(slab), _lib.ptr(self.tile_g), _lib.ptr(self.tile_col0),
-                           _lib.ptr(self.g_ncols), _lib.ptr(tb["g_choff"]), _lib.ptr(self.wg_chan_rows),
-                           _lib.ptr(self.dz_rows), self.n_tiles, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"],
+        d = _lib.WgradDesc(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(slab), _lib.ptr(t.tile_g), _lib.ptr(t.tile_col0),
+                           _lib.ptr(t.g_ncols), _lib.ptr(tb["g_choff"]), _lib.ptr(t.chan_rows),
+                           _lib.ptr(t.dz_rows), t.n_tiles, g.n_groups, g.mt, g.kt, ns, ge["t_dst"], ge["t_src"],
                            ge["stride"], ge["pad"], ge["pad_mode"], int(bp), self.y_ts, self.x_ts, 0, *self._wg_items(bp),
                            *self._plane_args(dy, x, bp), fused, *self._pair_args(bp))
         _lib.check(lib.hmvae_wgrad_gemm(C.byref(d), _lib.stream()), "wgrad_gemm")
@@ -1150,9 +1244,10 @@ class MaskedGemm:
         return (_lib.ptr(sc["items"]), _lib.ptr(sc["worker_items"]), sc["n_workers"], self.desc_mode(bp))
 
     def _pair_args(self, bp):
-        if self.wg_mode(bp) != 3:
+        md = self.wg_mode(bp)
+        if md not in (3, 4):
             return (None, 0, 0)
-        tab, n = self.pair_tab()
+        tab, n = self.pair_tab(self.wide()) if md == 4 else self.pair_tab()
         return (_lib.ptr(tab), n, 0)
 
     def _wg_parts(self, bp):

@@ -813,3 +813,60 @@ def test_wgrad_lds_staged_kernel_matches_direct(dev, monkeypatch, cfg):
     # product instead of once per term)
     assert max(worst.values()) < 2e-6, worst
     assert max(worst[m] for m in modes if m in ("2", "3")) <= 1.5 * worst["0"] + 1e-7, worst
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(rows=28, ch=12, neigh=[[0, 1, 2, 3]] * 4, kt=15, stride=1, pad=7, mode="reflect", t_in=8, B=70),      # 112 rows: mt 7
+    dict(rows=24, ch=12, neigh=[[0, 1, 2, 3]] * 4, kt=15, stride=2, pad=7, mode="reflect", t_in=16, B=64),     # 96 rows: mt 6
+    dict(rows=20, ch=6, neigh=[[0, 1, 2, 3]] * 4, kt=15, stride=1, pad=7, mode="zeros", t_in=9, B=33),         # 80 rows: mt 5
+    dict(rows=28, ch=12, neigh=[[0, 1, 2, 3], [0, 1, 2, 3], [0, 1, 2, 3], [2, 3]], kt=15, stride=2, pad=7,
+         mode="reflect", t_in=12, B=130),                                               # blocks read by 84 / 112 rows: dead row tiles
+])
+def test_wgrad_wide_tiles_match_float64(dev, monkeypatch, cfg):
+    """wg_mode 4 (wgrad_bf3w_kernel: up to 112 rows x 128 columns per 8-wave workgroup, three bf16 planes, six cross
+    terms): every row-tile count 5..7, groups with dead row tiles, a group's unpaired last column tile, ragged batches,
+    zero padding, the fused epilogue (split 1) and the slab + reduce route (split 2), accumulate -- against a float64
+    evaluation of the convolution's weight gradient (skeleton.py:95-105) and against the 48 x 64 kernel (mode 2)."""
+    from hm_vae_amd import ops
+    nj = len(cfg["neigh"])
+    cin, cout = nj * cfg["ch"], nj * cfg["rows"]
+    op = ops.conv_gemm(dev, cfg["neigh"], cin, cout, cfg["kt"], cfg["stride"], cfg["pad"], cfg["mode"], cfg["t_in"], need_dx=True)
+    w = op.wide()
+    assert w is not None and w.g.mt in (5, 6, 7), None if w is None else w.g.mt
+    B = cfg["B"]
+    bp = ops.pad_batch(B)
+    t_out = op.t_out
+    x = torch.zeros(cin * cfg["t_in"], bp, device=dev)
+    dy = torch.zeros(cout * t_out, bp, device=dev)
+    x[:, :B] = torch.randn(cin * cfg["t_in"], B, device=dev)
+    dy[:, :B] = torch.randn(cout * t_out, B, device=dev)
+    slab = torch.empty(op.slab_floats(bp), device=dev)
+    monkeypatch.setattr(ops, "AUTOTUNE", False)
+    xb = x[:, :B].reshape(cin, cfg["t_in"], B).permute(2, 0, 1).double().cpu()
+    gb = dy[:, :B].reshape(cout, t_out, B).permute(2, 0, 1).double().cpu()
+    wt = torch.zeros(cout, cin, cfg["kt"], dtype=torch.float64, requires_grad=True)
+    mask = O.conv_mask(cfg["neigh"], cin, cout, cfg["kt"]).double()
+    (O.skel_conv(xb, wt, mask, None, cfg["stride"], cfg["pad"], O._pad_mode(cfg["mode"])) * gb).sum().backward()
+    exact = wt.grad.numpy()
+    res = {}
+    for mode, splits in (("2", (1,)), ("4", (1, 2))):
+        monkeypatch.setattr(ops, "WGRAD_LDS", mode)
+        for split in splits:
+            if split > 1 and split not in op.split_candidates(bp):
+                continue
+            op._split_tuned[bp] = split
+            dw = torch.full((cout, cin, cfg["kt"]), 7.0, device=dev) * torch.from_numpy(mask.numpy()).float().to(dev)
+            op.backward_weight(dy, x, dw, bp, slab)
+            assert op.wg_mode(bp) == int(mode) and op.fusable(bp) == (split == 1)
+            res[(mode, split)] = dw.cpu().numpy()
+            assert rel_err(res[(mode, split)], exact) < 2e-6, (mode, split)
+            assert float(np.abs(res[(mode, split)] * (1 - mask.numpy())).max()) == 0.0
+    assert ("4", 1) in res
+    for k, v in res.items():
+        assert rel_err(v, res[("2", 1)]) < 2e-6, k
+    # accumulate: dW += (fused epilogue)
+    monkeypatch.setattr(ops, "WGRAD_LDS", "4")
+    op._split_tuned[bp] = 1
+    dw = torch.from_numpy(res[("4", 1)]).to(dev).clone()
+    op.backward_weight(dy, x, dw, bp, slab, accumulate=True)
+    assert rel_err(dw.cpu().numpy(), 2.0 * exact) < 2e-6

@@ -177,6 +177,8 @@ def main():
                     ([3] if (ops.WGRAD_BF3 and obj.lds_eligible() and obj.pair_eligible()) else [])
                 splits = [c for c in obj.split_candidates(bp) if not a.fast or c in (1, 2, 3, 4, 6, 8)]
                 cands = [(c, m) for m in modes for c in splits if (c, m) != cur]
+                if ops.WGRAD_BF3 and obj.lds_eligible() and obj.wide() is not None:      # wide tiles: their own short list of splits
+                    cands += [(c, 4) for c in obj.wide_split_candidates(bp) if c in obj.split_candidates(bp) and (c, 4) != cur]
                 best_c, best_t = cur, base
                 for c, m in cands:
                     if VERBOSE:
