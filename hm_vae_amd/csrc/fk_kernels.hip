@@ -117,15 +117,22 @@ __device__ __forceinline__ V3 cross_f(V3 u, V3 v) {
 }
 __device__ __forceinline__ float dot_f(V3 u, V3 v) { return u.x * v.x + u.y * v.y + u.z * v.z; }
 
-// backward of lift6d: given the 6D input and dL/dR, return dL/d(in)
+// backward of lift6d: given the 6D input and dL/dR, return dL/d(in).
+// (round 3) The two projections are SCALED by one reciprocal per vector instead of divided component by component (an IEEE
+// fp32 division is ~11 instructions, the backward kernels run this function twice per joint and are bound by vector-
+// instruction issue): a relative ulp on an output.  The unit vectors x and z themselves keep the reference's divisions:
+// they feed the cancelling differences dz - z (z . dz), and on the ill-conditioned rows of the reference fixture (nearly
+// parallel 6D vectors) a reciprocal-multiplied z moved the gradient by 2e-3 of its largest entry.
 __device__ __forceinline__ void lift6d_bwd(const float* in, const M3& dR, float* din) {
     const V3 a = {in[0], in[1], in[2]}, b = {in[3], in[4], in[5]};
     const float na_raw = norm_exact(a);
     const float na = fmaxf(na_raw, kEps);
+    const float ina = 1.f / na;
     const V3 x = {a.x / na, a.y / na, a.z / na};
     const V3 zr = cross_exact(x, b);
     const float nz_raw = norm_exact(zr);
     const float nz = fmaxf(nz_raw, kEps);
+    const float inz = 1.f / nz;
     const V3 z = {zr.x / nz, zr.y / nz, zr.z / nz};
     V3 dx = {dR.a[0], dR.a[3], dR.a[6]};
     const V3 dy = {dR.a[1], dR.a[4], dR.a[7]};
@@ -137,9 +144,9 @@ __device__ __forceinline__ void lift6d_bwd(const float* in, const M3& dR, float*
     V3 dzr;
     if (nz_raw >= kEps) {
         const float s = dot_f(z, dz);
-        dzr = {(dz.x - z.x * s) / nz, (dz.y - z.y * s) / nz, (dz.z - z.z * s) / nz};
+        dzr = {(dz.x - z.x * s) * inz, (dz.y - z.y * s) * inz, (dz.z - z.z * s) * inz};
     } else {
-        dzr = {dz.x / kEps, dz.y / kEps, dz.z / kEps};
+        dzr = {dz.x * inz, dz.y * inz, dz.z * inz};
     }
     // zr = x × b
     dx = dx + cross_f(b, dzr);
@@ -148,9 +155,9 @@ __device__ __forceinline__ void lift6d_bwd(const float* in, const M3& dR, float*
     V3 da;
     if (na_raw >= kEps) {
         const float s = dot_f(x, dx);
-        da = {(dx.x - x.x * s) / na, (dx.y - x.y * s) / na, (dx.z - x.z * s) / na};
+        da = {(dx.x - x.x * s) * ina, (dx.y - x.y * s) * ina, (dx.z - x.z * s) * ina};
     } else {
-        da = {dx.x / kEps, dx.y / kEps, dx.z / kEps};
+        da = {dx.x * ina, dx.y * ina, dx.z * ina};
     }
     din[0] = da.x; din[1] = da.y; din[2] = da.z;
     din[3] = db.x; din[4] = db.y; din[5] = db.z;
@@ -385,13 +392,50 @@ __device__ __forceinline__ void fk_stream_out(const float* lds, float* __restric
     }
 }
 
+// 6D input of a 32-frame tile straight from global memory into the image of lifted matrices (rows LR apart); KEEP: the
+// thread's inputs are also returned (the backward's phase C lifts them again), pair k of thread t = t + 256 k.
+struct __attribute__((packed, aligned(4))) F3u { float x, y, z; };
+template <bool WRITE>
+__device__ __forceinline__ void fk_lift_in(const float* __restrict__ src, int nf, float* sR, float (*keep)[6]) {
+    constexpr int LR = NJ * 9 + 1;
+    constexpr int PAIRS = NJ * FK_FRAMES / 256;
+    float in[PAIRS][6];
+#pragma unroll
+    for (int k = 0; k < PAIRS; ++k) {
+        const int p = threadIdx.x + 256 * k;
+        if (p < nf * NJ) {
+            const float2* q = (const float2*)(src + 6 * (size_t)p);
+            const float2 a = q[0], b = q[1], c = q[2];
+            in[k][0] = a.x; in[k][1] = a.y; in[k][2] = b.x; in[k][3] = b.y; in[k][4] = c.x; in[k][5] = c.y;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) in[k][i] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PAIRS; ++k) {
+        const int p = threadIdx.x + 256 * k;
+        if (keep) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) keep[k][i] = in[k][i];
+        }
+        if (WRITE && p < nf * NJ) {
+            const int f = p / NJ, j = p - f * NJ;
+            M3 Rm;
+            lift6d(in[k], Rm);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sR[f * LR + j * 9 + i] = Rm.a[i];
+        }
+    }
+}
+
 // PF: per-frame offsets (off_stride = 72) instead of one shared set.  Either way the offsets are staged in LDS with the
 // tile: read from global inside the chain they cost five dependent L2 round trips per workgroup.
 template <int RD, bool PF>
 __global__ __launch_bounds__(256) void fk_fwd_aos_kernel(const float* __restrict__ rot, const float* __restrict__ offs,
                                                          long long n, float* __restrict__ R_out,
                                                          float* __restrict__ P_out) {
-    constexpr int LR = NJ * 9 + 1, LP = NJ * 3 + 1, L6 = NJ * 6 + 1;
+    constexpr int LR = NJ * 9 + 1, LP = NJ * 3 + 1;
     __shared__ float sR[FK_FRAMES * LR];
     __shared__ float sP[FK_FRAMES * LP];
     __shared__ float sO[PF ? FK_FRAMES * LP : NJ * 3];
@@ -404,32 +448,12 @@ __global__ __launch_bounds__(256) void fk_fwd_aos_kernel(const float* __restrict
     if constexpr (RD == 9) {
         fk_stream_in<NJ * 9>(rot + f0 * (NJ * 9), sR, nf);
     } else {
-        // the 6D image lives in the front of sR's space (32 x 145 of its 32 x 217 floats): every thread pulls its three
-        // inputs into registers, one barrier, then the lifted matrices overwrite the image.  A separate 18 KB buffer
-        // would leave two instead of four workgroups per CU.
-        float* s6 = sR;
-        fk_stream_in<NJ * 6>(rot + f0 * (NJ * 6), s6, nf);
-        __syncthreads();
-        const int f = threadIdx.x & (FK_FRAMES - 1);
-        constexpr int LIFTS = NJ * FK_FRAMES / 256;
-        float in[LIFTS][6];
-#pragma unroll
-        for (int i = 0; i < LIFTS; ++i) {
-            const int j = (threadIdx.x / FK_FRAMES) + i * (256 / FK_FRAMES);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) in[i][k] = s6[f * L6 + j * 6 + k];
-        }
-        __syncthreads();
-        if (f < nf) {
-#pragma unroll
-            for (int i = 0; i < LIFTS; ++i) {
-                const int j = (threadIdx.x / FK_FRAMES) + i * (256 / FK_FRAMES);
-                M3 Rm;
-                lift6d(in[i], Rm);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) sR[f * LR + j * 9 + k] = Rm.a[k];
-            }
-        }
+        // (round 3) A (frame, joint) pair's six floats are 24 contiguous, 8-byte aligned bytes of the frame-major input, and the
+        // pairs of a workgroup's 32 frames are ONE contiguous run: thread t takes pairs t, t + 256, t + 512 with three 8-byte
+        // loads each and lifts them in registers straight into the matrix image.  The round-2 form staged a 6D image in LDS
+        // first (16-byte loads, four scalar LDS writes each, barrier, 18 scalar LDS reads, barrier): 57-61 us at 262 144
+        // frames against 48-51 for the matrix-input variant that moves a third more bytes.
+        fk_lift_in<true>(rot + f0 * (NJ * 6), nf, sR, nullptr);
     }
     if constexpr (PF) fk_stream_in<NJ * 3>(offs + f0 * (NJ * 3), sO, nf);
     else if (threadIdx.x < NJ * 3) sO[threadIdx.x] = o_sh;
@@ -603,119 +627,275 @@ __device__ __forceinline__ void fk_bwd_by_role(int role, int lane, bool live, IO
 //      B  the chain by subtree (fk_bwd_by_role) on the LIFTED rotations; a joint's total dL/dR replaces its dL/dR row;
 //      C  RD == 6: the lift's backward for three joints per thread, in parallel; stream the gradient out.
 //      dL/dp is read from global memory inside the chain (three floats per joint: it does not fit the tile twice over).
+// The same subtree split WITHOUT the template recursion (round 3): every limb of the SMPL-24 tree is a path, so a wave walks
+// its path down once -- keeping the parents' global rotations (9 registers per level, <= 5 levels) and the position
+// gradients -- and up once with the running sums (S, H): ~110 registers where the recursive walk above holds 270 (it keeps
+// every level's whole frame alive), which is what lets the single-image kernels below keep their phase-A values in
+// registers at two / three waves per SIMD.  Same arithmetic, same order of the sums per joint.  The policy's emit() receives
+// what the chain ADDS to a joint's dL/dR (G_parent^T H_j); direct dL/dR terms are the caller's.
+template <int N, class IO>
+__device__ __forceinline__ void fk_path_bwd(const int (&J)[N], const M3& Gp0, V3 Pp0, IO& io, V3& S, M3& H) {
+    M3 Gp[N];
+    V3 dP[N];
+    Gp[0] = Gp0;
+    V3 P = Pp0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        P = P + mulv(Gp[i], io.off(J[i]));
+        dP[i] = io.grad_P(J[i], P);
+        if (i + 1 < N) {
+            M3 R;
+            io.rot(J[i], R);
+            Gp[i + 1] = mul(Gp[i], R);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // one joint at a time: hoisting every level's loads costs 60+ registers
+    }
+    V3 Sc = {0.f, 0.f, 0.f};
+    M3 Hc;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Hc.a[k] = 0.f;
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        Sc = Sc + dP[i];
+        M3 R;
+        io.rot(J[i], R);
+        io.emit(J[i], mul_tn(Gp[i], Hc));
+        M3 up = mul_nt(Hc, R);                      // what the parent's H receives: H R^T + S (x) off
+        add_outer(up, Sc, io.off(J[i]));
+        Hc = up;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    S = S + Sc;
+    add_m(H, Hc);
+}
+
+template <int FR, class IO>
+__device__ __forceinline__ void fk_bwd_by_role2(int role, int lane, bool live, IO& io, float (*xch)[12][FR]) {
+    constexpr int LEG_L[4] = {1, 4, 7, 10}, LEG_R[4] = {2, 5, 8, 11}, HEAD[2] = {12, 15};
+    constexpr int ARM_L[5] = {13, 16, 18, 20, 22}, ARM_R[5] = {14, 17, 19, 21, 23};
+    // the trunk's forward chain is three 3x3 products: every wave computes what its limb hangs off, and wave 0 computes it
+    // AGAIN after the barrier instead of holding four matrices and four positions across its head path
+    auto trunk_to_9 = [&](M3& G6o, M3& G9o, V3& P9o) {
+        M3 G0, G3, R;
+        io.rot(0, G0);
+        const V3 P0 = io.off(0);
+        io.rot(3, R);
+        const V3 P3 = P0 + mulv(G0, io.off(3));
+        G3 = mul(G0, R);
+        io.rot(6, R);
+        const V3 P6 = P3 + mulv(G3, io.off(6));
+        G6o = mul(G3, R);
+        io.rot(9, R);
+        P9o = P6 + mulv(G6o, io.off(9));
+        G9o = mul(G6o, R);
+    };
+    if (live) {
+        V3 S = {0.f, 0.f, 0.f};
+        M3 H;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) H.a[i] = 0.f;
+        if (role == 1) {
+            M3 G0;
+            io.rot(0, G0);
+            const V3 P0 = io.off(0);
+            fk_path_bwd(LEG_L, G0, P0, io, S, H);
+            fk_path_bwd(LEG_R, G0, P0, io, S, H);
+        } else {
+            M3 G6, G9;
+            V3 P9;
+            trunk_to_9(G6, G9, P9);
+            if (role == 2) fk_path_bwd(ARM_L, G9, P9, io, S, H);
+            else if (role == 3) fk_path_bwd(ARM_R, G9, P9, io, S, H);
+            else fk_path_bwd(HEAD, G9, P9, io, S, H);
+        }
+        xch[role][0][lane] = S.x;
+        xch[role][1][lane] = S.y;
+        xch[role][2][lane] = S.z;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) xch[role][3 + i][lane] = H.a[i];
+    }
+    __syncthreads();
+    if (role == 0 && live) {
+        auto take = [&](int slot, V3& S, M3& H) {
+            S = S + V3{xch[slot][0][lane], xch[slot][1][lane], xch[slot][2][lane]};
+#pragma unroll
+            for (int i = 0; i < 9; ++i) H.a[i] += xch[slot][3 + i][lane];
+        };
+        // trunk joint J (parent rotation Gp, position P): H holds the sums over its children
+        auto node = [&](int J, const M3& Gp, V3 P, V3& S, M3& H, bool root) {
+            S = S + io.grad_P(J, P);
+            M3 R;
+            io.rot(J, R);
+            io.emit(J, root ? H : mul_tn(Gp, H));
+            M3 up = mul_nt(H, R);
+            add_outer(up, S, io.off(J));
+            H = up;
+        };
+        M3 G0, G3, G6, R;
+        io.rot(0, G0);
+        const V3 P0 = io.off(0);
+        io.rot(3, R);
+        const V3 P3 = P0 + mulv(G0, io.off(3));
+        G3 = mul(G0, R);
+        io.rot(6, R);
+        const V3 P6 = P3 + mulv(G3, io.off(6));
+        G6 = mul(G3, R);
+        const V3 P9 = P6 + mulv(G6, io.off(9));
+        V3 S = {0.f, 0.f, 0.f};
+        M3 H;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) H.a[i] = 0.f;
+        take(0, S, H);                                 // head, left arm, right arm hang off joint 9
+        take(2, S, H);
+        take(3, S, H);
+        node(9, G6, P9, S, H, false);
+        node(6, G3, P6, S, H, false);
+        node(3, G0, P3, S, H, false);
+        take(1, S, H);                                 // the legs hang off the root
+        node(0, G0, P0, S, H, true);
+    }
+}
+
+// Phase B policy of the single-image backward kernels (round 3): rotations come from the LDS image; what the chain ADDS to a
+// joint's dL/dR (G_parent^T H_j) replaces the joint's rotation in the image once the joint is done with it -- a limb joint is
+// read by its own wave only, and the trunk's rotations are read by every wave BEFORE fk_bwd_by_role's barrier and replaced by
+// wave 0 after it.  The direct dL/dR stays with the threads of phases A / C.  One image instead of two: twice the workgroups
+// per CU, and these kernels are chains of dependent LDS round trips that only other workgroups can hide.
 template <bool PF>
-struct LdsBwd {
-    const float* R;        // LDS row of this frame: lifted rotations, J*9
+struct LdsBwd1 {
+    float* R;              // LDS row of this frame: lifted rotations in, induced dL/dR out (J*9)
     const float* offs;     // LDS: J*3 (shared or this frame's)
-    float* dR;             // LDS row J*9: dL/dR from upstream (zeros if absent) in, total dL/dR out
-    const float* dP_up;    // global row J*3 of this frame, or nullptr
+    const float* dP;       // LDS row J*3: dL/dp (zeros if absent)
     __device__ __forceinline__ void rot(int j, M3& Rm) const {
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rm.a[k] = R[j * 9 + k];
     }
     __device__ __forceinline__ V3 off(int j) const { return {offs[j * 3], offs[j * 3 + 1], offs[j * 3 + 2]}; }
-    __device__ __forceinline__ V3 grad_P(int j, V3) const {
-        if (dP_up) return {dP_up[j * 3], dP_up[j * 3 + 1], dP_up[j * 3 + 2]};
-        return {0.f, 0.f, 0.f};
-    }
-    __device__ __forceinline__ void grad_R(int j, const M3&, M3& g) const {
+    __device__ __forceinline__ V3 grad_P(int j, V3) const { return {dP[j * 3], dP[j * 3 + 1], dP[j * 3 + 2]}; }
+    __device__ __forceinline__ void grad_R(int, const M3&, M3& g) const {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) g.a[k] = dR[j * 9 + k];
+        for (int k = 0; k < 9; ++k) g.a[k] = 0.f;
     }
     __device__ __forceinline__ void emit(int j, const M3& g) const {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) dR[j * 9 + k] = g.a[k];
+        for (int k = 0; k < 9; ++k) R[j * 9 + k] = g.a[k];
     }
 };
 
+// Backward of ForwardKinematicsLayer (+ the 6D lift) on frame-major tensors.  History of this kernel (262 144 frames,
+// 6D input, 2 304 algorithmic bytes per frame):
+//   1. a thread per frame straight on global memory: every load / store instruction touched 64 different 576-byte frames
+//      and the chain was a 24-joint serial walk that lifted every rotation three times -- 491 us;
+//   2. 32-frame LDS tiles + the subtree split of fk_bwd_by_role, lifts still inside the chain: 565 us -- not the memory
+//      access but the chain's instruction count and its 273 registers (one wave per SIMD) were the limit; the same code
+//      compiled for two waves per SIMD (30 spills) ran 336 us;
+//   3. three phases over the LDS tile, so that the serial part is 3x3 algebra only (round 2: 238-252 us):
+//      A  the rotations in; RD == 6: lift them, three joints per thread, inputs kept in registers;
+//      B  the chain by subtree (fk_bwd_by_role) on the LIFTED rotations;
+//      C  RD == 6: the lift's backward for three joints per thread, in parallel; the gradient out;
+//   4. (this version, round 3) ONE image: the (frame, joint) pairs of a tile are one contiguous run of the frame-major
+//      tensors, so thread t reads pairs t, t + 256, t + 512 straight from global memory (24 bytes of 6D, 36 of dL/dR: kept
+//      in registers, never staged), the chain leaves the induced dL/dR in the rotations' place (LdsBwd1), dL/dp is a
+//      third, small image instead of stride-288 reads inside the chain, and phase C stores its 24 bytes per pair itself.
 #ifndef FK_BWD_OCC
-#define FK_BWD_OCC 2
+#define FK_BWD_OCC 3
 #endif
 template <int RD, bool PF>
 __global__ __launch_bounds__(256, FK_BWD_OCC) void fk_bwd_aos_kernel(const float* __restrict__ rot, const float* __restrict__ offs,
                                                          long long n, const float* __restrict__ dR_up,
                                                          const float* __restrict__ dP_up, float* __restrict__ d_rot) {
-    constexpr int L6 = NJ * 6 + 1, LR = NJ * 9 + 1, LP = NJ * 3 + 1;
-    constexpr int LIFTS = NJ * FK_FRAMES / 256;          // joints per thread in the parallel phases
+    constexpr int LR = NJ * 9 + 1, LP = NJ * 3 + 1;
+    constexpr int PAIRS = NJ * FK_FRAMES / 256;          // (frame, joint) pairs per thread in the parallel phases
     extern __shared__ __attribute__((aligned(16))) float fk_lds[];
-    float* sR = fk_lds;                                  // rotations (RD == 6: first the 6D image, last the 6D gradient)
-    float* sD = sR + FK_FRAMES * LR;                     // dL/dR
-    float* sO = sD + FK_FRAMES * LR;                     // offsets
+    float* sR = fk_lds;                                  // rotations, then the induced dL/dR
+    float* sP = sR + FK_FRAMES * LR;                     // dL/dp
+    float* sO = sP + FK_FRAMES * LP;                     // offsets
     float (*xch)[12][FK_FRAMES] = (float (*)[12][FK_FRAMES])(sO + (PF ? FK_FRAMES * LP : NJ * 3 + 1));
     const long long f0 = (long long)blockIdx.x * FK_FRAMES;
     const int nf = n - f0 < FK_FRAMES ? (int)(n - f0) : FK_FRAMES;
-    const int f = threadIdx.x & (FK_FRAMES - 1);
     float o_sh = 0.f;
     if constexpr (!PF) {
         if (threadIdx.x < NJ * 3) o_sh = offs[threadIdx.x];
     }
     // ---- A ----
-    float in[RD == 6 ? LIFTS : 1][6];
-    if constexpr (RD == 9) fk_stream_in<NJ * 9>(rot + f0 * (NJ * 9), sR, nf);
-    else fk_stream_in<NJ * 6>(rot + f0 * (NJ * 6), sR, nf);
-    if (dR_up) {
-        fk_stream_in<NJ * 9>(dR_up + f0 * (NJ * 9), sD, nf);
+    float in[RD == 6 ? PAIRS : 1][6];
+    float dd[RD == 6 ? PAIRS : 1][6];                    // the DIRECT dL/dR of this thread's pairs, already through the lift's
+                                                         // backward (it is linear in dL/dR): 6 instead of 9 values across the chain
+    if constexpr (RD == 6) {
+        float dRd[PAIRS][9];
+#pragma unroll
+        for (int k = 0; k < PAIRS; ++k) {
+            const int p = threadIdx.x + 256 * k;
+            if (dR_up && p < nf * NJ) {
+                const F3u* q = (const F3u*)(dR_up + f0 * (NJ * 9) + 9 * (size_t)p);
+                const F3u a = q[0], b = q[1], c = q[2];
+                dRd[k][0] = a.x; dRd[k][1] = a.y; dRd[k][2] = a.z; dRd[k][3] = b.x; dRd[k][4] = b.y; dRd[k][5] = b.z;
+                dRd[k][6] = c.x; dRd[k][7] = c.y; dRd[k][8] = c.z;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) dRd[k][i] = 0.f;
+            }
+        }
+        fk_lift_in<true>(rot + f0 * (NJ * 6), nf, sR, in);
+#pragma unroll
+        for (int k = 0; k < PAIRS; ++k) {
+            M3 g;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) g.a[i] = dRd[k][i];
+            lift6d_bwd(in[k], g, dd[k]);
+        }
     } else {
-        for (int i = threadIdx.x; i < FK_FRAMES * LR; i += 256) sD[i] = 0.f;
+        fk_stream_in<NJ * 9>(rot + f0 * (NJ * 9), sR, nf);
+    }
+    if (dP_up) {
+        fk_stream_in<NJ * 3>(dP_up + f0 * (NJ * 3), sP, nf);
+    } else {
+        for (int i = threadIdx.x; i < FK_FRAMES * LP; i += 256) sP[i] = 0.f;
     }
     if constexpr (PF) fk_stream_in<NJ * 3>(offs + f0 * (NJ * 3), sO, nf);
     else if (threadIdx.x < NJ * 3) sO[threadIdx.x] = o_sh;
-    if constexpr (RD == 6) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < LIFTS; ++i) {
-            const int j = (threadIdx.x / FK_FRAMES) + i * (256 / FK_FRAMES);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) in[i][k] = sR[f * L6 + j * 6 + k];
-        }
-        __syncthreads();
-        if (f < nf) {
-#pragma unroll
-            for (int i = 0; i < LIFTS; ++i) {
-                const int j = (threadIdx.x / FK_FRAMES) + i * (256 / FK_FRAMES);
-                M3 Rm;
-                lift6d(in[i], Rm);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) sR[f * LR + j * 9 + k] = Rm.a[k];
-            }
-        }
-    }
     __syncthreads();
     // ---- B ----
     {
         const int lane = threadIdx.x & 63;
         const bool live = lane < nf;
         const int fl = live ? lane : 0;
-        LdsBwd<PF> io{sR + fl * LR, PF ? sO + fl * LP : sO, sD + fl * LR, dP_up ? dP_up + (f0 + fl) * (NJ * 3) : nullptr};
-        fk_bwd_by_role<FK_FRAMES>(threadIdx.x >> 6, fl, live, io, xch);
+        LdsBwd1<PF> io{sR + fl * LR, PF ? sO + fl * LP : sO, sP + fl * LP};
+        fk_bwd_by_role2<FK_FRAMES>(threadIdx.x >> 6, fl, live, io, xch);
     }
     __syncthreads();
     // ---- C ----
     if constexpr (RD == 6) {
-        float din[LIFTS][6];
-        if (f < nf) {
 #pragma unroll
-            for (int i = 0; i < LIFTS; ++i) {
-                const int j = (threadIdx.x / FK_FRAMES) + i * (256 / FK_FRAMES);
+        for (int k = 0; k < PAIRS; ++k) {
+            const int p = threadIdx.x + 256 * k;
+            if (p < nf * NJ) {
+                const int f = p / NJ, j = p - f * NJ;
                 M3 g;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) g.a[k] = sD[f * LR + j * 9 + k];
-                lift6d_bwd(in[i], g, din[i]);
+                for (int i = 0; i < 9; ++i) g.a[i] = sR[f * LR + j * 9 + i];
+                float din[6];
+                lift6d_bwd(in[k], g, din);
+                float2* q = (float2*)(d_rot + f0 * (NJ * 6) + 6 * (size_t)p);
+                q[0] = float2{din[0] + dd[k][0], din[1] + dd[k][1]};
+                q[1] = float2{din[2] + dd[k][2], din[3] + dd[k][3]};
+                q[2] = float2{din[4] + dd[k][4], din[5] + dd[k][5]};
             }
         }
-        // the 6D gradient image goes where the rotations were (rows of L6 floats): nobody reads them any more
-        if (f < nf) {
-#pragma unroll
-            for (int i = 0; i < LIFTS; ++i) {
-                const int j = (threadIdx.x / FK_FRAMES) + i * (256 / FK_FRAMES);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) sR[f * L6 + j * 6 + k] = din[i][k];
-            }
-        }
-        __syncthreads();
-        fk_stream_out<NJ * 6>(sR, d_rot + f0 * (NJ * 6), nf);
     } else {
-        fk_stream_out<NJ * 9>(sD, d_rot + f0 * (NJ * 9), nf);
+        // total = upstream + induced, 16-byte pieces in the tensor's own order
+        const float* up = dR_up ? dR_up + f0 * (NJ * 9) : nullptr;
+        float* dst = d_rot + f0 * (NJ * 9);
+        for (int i = threadIdx.x; i < nf * (NJ * 9 / 4); i += 256) {
+            const int f = i / (NJ * 9 / 4), q = i - f * (NJ * 9 / 4);
+            const float* l = sR + f * LR + 4 * q;
+            float4 v = float4{l[0], l[1], l[2], l[3]};
+            if (up) {
+                const float4 u = *(const float4*)(up + (size_t)f * (NJ * 9) + 4 * q);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            *(float4*)(dst + (size_t)f * (NJ * 9) + 4 * q) = v;
+        }
     }
 }
 
@@ -957,7 +1137,7 @@ extern "C" int hmvae_fk_bwd(const float* rot, int32_t rot_dim, const float* offs
         return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
     }
     dim3 grid((unsigned)((n_frames + FK_FRAMES - 1) / FK_FRAMES)), block(256);
-    const size_t lds = sizeof(float) * (FK_FRAMES * 2 * (NJ * 9 + 1) + (pf ? FK_FRAMES * (NJ * 3 + 1) : NJ * 3 + 1) +
+    const size_t lds = sizeof(float) * (FK_FRAMES * ((NJ * 9 + 1) + (NJ * 3 + 1)) + (pf ? FK_FRAMES * (NJ * 3 + 1) : NJ * 3 + 1) +
                                         4 * 12 * FK_FRAMES);
 #define FK_BWD_LAUNCH(RD_, PF_)                                                                                        \
     {                                                                                                                  \
@@ -1142,9 +1322,11 @@ struct TailChain {
         sP += ex * ex + ey * ey + ez * ez;
         return {cP * ex, cP * ey, cP * ez};
     }
-    __device__ __forceinline__ void grad_R(int j, const M3&, M3& g) const {
+    // (round 3) dR is the rotations' own row: the chain leaves what it ADDS to a joint's dL/dR where the joint's rotation was
+    // (see LdsBwd1); the direct dL/dR stays in the registers of phases A / C
+    __device__ __forceinline__ void grad_R(int, const M3&, M3& g) const {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) g.a[k] = dR[j * 9 + k];
+        for (int k = 0; k < 9; ++k) g.a[k] = 0.f;
     }
     __device__ __forceinline__ void emit(int j, const M3& g) const {
 #pragma unroll
@@ -1153,33 +1335,42 @@ struct TailChain {
 };
 
 constexpr int TL3_LR = NJ * 9 + 1;                   // odd row length: conflict-free per-frame accesses
-constexpr int TL3_JT = NJ * TL_FRAMES / 256;         // joints per thread in the parallel phases (6)
-template <bool MK>
-__global__ __launch_bounds__(256) void decode_tail_loss3_kernel(const float* __restrict__ dec, const float* __restrict__ g6,
+#ifndef TL3_FR_DEFAULT
+#define TL3_FR_DEFAULT 64        // measured at 262 144 frames: 239 us (64) against 307 us (32)
+#endif
+// FR: frames (batch columns) per workgroup.  64: full waves in the chain phase, six joints per thread in the parallel phases;
+// 32: half-empty waves in the chain but three joints per thread (63 instead of 126 values held across the chain) and 34 KB of
+// LDS -- three workgroups per CU whose chain phases hide behind each other's parallel phases.
+template <bool MK, int FR>
+__global__ __launch_bounds__(256, FR == 64 ? 2 : 3) void decode_tail_loss3_kernel(const float* __restrict__ dec, const float* __restrict__ g6,
                                                                 const float* __restrict__ gR, const float* __restrict__ gP,
                                                                 const float* __restrict__ mask,
                                                                 const float* __restrict__ offs, int T, int B, int bp,
                                                                 float c6, float cR, float cP, float* __restrict__ ddec,
                                                                 float* __restrict__ partial) {
+    constexpr int TL3_JT = NJ * FR / 256;             // joints per thread in the parallel phases
+    constexpr int JS = 256 / FR;                      // joint stride between a thread's joints
     extern __shared__ __attribute__((aligned(16))) float tl3[];
-    float* sR = tl3;                                             // [TL_FRAMES][TL3_LR] lifted rotations
-    float* sD = sR + TL_FRAMES * TL3_LR;                         // [TL_FRAMES][TL3_LR] dL/dR
-    float (*xch)[12][TL_FRAMES] = (float (*)[12][TL_FRAMES])(sD + TL_FRAMES * TL3_LR);
+    float* sR = tl3;                                             // [FR][TL3_LR] lifted rotations, then the induced dL/dR
+    float (*xch)[12][FR] = (float (*)[12][FR])(sR + FR * TL3_LR);
     float (*psum)[3] = (float (*)[3])(&xch[4][0][0]);
-    const int f = threadIdx.x & 63;
-    const int jg = threadIdx.x >> 6;                  // wave-uniform: joints jg, jg + 4, ... in the parallel phases, the role in B
-    const int b = blockIdx.x * TL_FRAMES + f;
+    const int f = threadIdx.x & (FR - 1);
+    const int jg = threadIdx.x / FR;                  // joints jg, jg + JS, ... in the parallel phases
+    const int b = blockIdx.x * FR + f;
     const int t = blockIdx.y;
     const size_t rs = (size_t)T * bp;
     const size_t o = (size_t)t * bp + b;
     const bool live = b < B;
+    // inputs and the DIRECT part of dL/d(6D) of this thread's joints: the 6D error plus the matrix error taken through the
+    // lift's backward right here (it is linear in dL/dR) -- 12 instead of 21 values per joint held across the chain
     float in[TL3_JT][6], d6[TL3_JT][6];
     float s6 = 0.f, sRs = 0.f;
     // ---- A ----
     if (live) {
 #pragma unroll
         for (int i = 0; i < TL3_JT; ++i) {
-            const int j = jg + 4 * i;
+            const int j = jg + JS * i;
+            M3 dRd;
             const float w = MK ? mask[o + (size_t)j * rs] : 1.f;
 #pragma unroll
             for (int k = 0; k < 6; ++k) in[i][k] = dec[o + (size_t)(j * 6 + k) * rs];
@@ -1197,25 +1388,40 @@ __global__ __launch_bounds__(256) void decode_tail_loss3_kernel(const float* __r
                 const float e = Rm.a[k] - gR[o + (size_t)(j * 9 + k) * rs];
                 aR += e * e;
                 sR[f * TL3_LR + j * 9 + k] = Rm.a[k];
-                sD[f * TL3_LR + j * 9 + k] = (MK ? cR * w : cR) * e;
+                dRd.a[k] = (MK ? cR * w : cR) * e;
+            }
+            {
+                float dl[6];
+                lift6d_bwd(in[i], dRd, dl);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) d6[i][k] += dl[k];
             }
             s6 += MK ? w * a6 : a6;
             sRs += MK ? w * aR : aR;
         }
     }
     __syncthreads();
-    // ---- B ----
-    TailChain<MK> io{sR + f * TL3_LR, sD + f * TL3_LR, gP + o, MK ? mask + o : nullptr, offs, rs, 0.f, cP};
-    fk_bwd_by_role<TL_FRAMES>(jg, f, live, io, xch);
+    // ---- B ---- (lanes = frames; with FR == 32 the upper half of every wave idles)
+    float sPs = 0.f;
+    {
+        const int lane = threadIdx.x & 63;
+        const int fb = lane & (FR - 1);
+        const int bb = blockIdx.x * FR + fb;
+        const bool lv = lane < FR && bb < B;
+        const size_t ob = (size_t)t * bp + bb;
+        TailChain<MK> io{sR + fb * TL3_LR, sR + fb * TL3_LR, gP + ob, MK ? mask + ob : nullptr, offs, rs, 0.f, cP};
+        fk_bwd_by_role2<FR>(threadIdx.x >> 6, fb, lv, io, xch);
+        sPs = lv ? io.sP : 0.f;
+    }
     __syncthreads();
     // ---- C ----
     if (live) {
 #pragma unroll
         for (int i = 0; i < TL3_JT; ++i) {
-            const int j = jg + 4 * i;
+            const int j = jg + JS * i;
             M3 g;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) g.a[k] = sD[f * TL3_LR + j * 9 + k];
+            for (int k = 0; k < 9; ++k) g.a[k] = sR[f * TL3_LR + j * 9 + k];
             float din[6];
             lift6d_bwd(in[i], g, din);
 #pragma unroll
@@ -1225,13 +1431,13 @@ __global__ __launch_bounds__(256) void decode_tail_loss3_kernel(const float* __r
 #pragma unroll
         for (int i = 0; i < TL3_JT; ++i)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) ddec[o + (size_t)((jg + 4 * i) * 6 + k) * rs] = 0.f;   // padded columns: zero gradient
+            for (int k = 0; k < 6; ++k) ddec[o + (size_t)((jg + JS * i) * 6 + k) * rs] = 0.f;   // padded columns: zero gradient
     }
-    const float w6 = wave_sum_f(s6), wR = wave_sum_f(sRs), wP = wave_sum_f(live ? io.sP : 0.f);
-    if (f == 0) {
-        psum[jg][0] = w6;
-        psum[jg][1] = wR;
-        psum[jg][2] = wP;
+    const float w6 = wave_sum_f(s6), wR = wave_sum_f(sRs), wP = wave_sum_f(sPs);
+    if ((threadIdx.x & 63) == 0) {
+        psum[threadIdx.x >> 6][0] = w6;
+        psum[threadIdx.x >> 6][1] = wR;
+        psum[threadIdx.x >> 6][2] = wP;
     }
     __syncthreads();
     if (threadIdx.x < 3) {
@@ -1303,8 +1509,11 @@ __global__ __launch_bounds__(256) void decode_tail_fwd_kernel(const float* __res
                                                               float* __restrict__ R, float* __restrict__ P) {
     constexpr int L6 = NJ * 6 + 1, LR = NJ * 9 + 1, LP = NJ * 3 + 1;
     constexpr int LIFTS = NJ * TF_FRAMES / 256;      // lifts per thread
-    __shared__ float s6[C6 ? TF_FRAMES * L6 : 1];
+    // (round 3) the frame-major 6D copy is streamed out of the FRONT of sR's space before the lifted matrices are written
+    // there -- two more barriers per group, but 37 instead of 56 KB of LDS: four workgroups per CU like the variant without
+    // the copy (72 instead of 36 KB of loads in flight per CU; bandwidth x latency asks for ~55)
     __shared__ float sR[TF_FRAMES * LR];
+    float* const s6 = sR;
     __shared__ float sP[TF_FRAMES * LP];
     __shared__ float sO[NJ * 3];                     // offsets: LDS broadcast reads inside the chain, no global round trips
     const size_t rs = (size_t)T * bp;
@@ -1339,30 +1548,7 @@ __global__ __launch_bounds__(256) void decode_tail_fwd_kernel(const float* __res
     for (int g = 0; g < TF_GROUPS; ++g) {
         const int t = t0 + g;
         if (t >= T) break;
-        // A: lifts
-#pragma unroll
-        for (int i = 0; i < LIFTS; ++i) {
-            const int j = j0 + i * (256 / TF_FRAMES);
-            if constexpr (C6) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) s6[f * L6 + j * 6 + k] = in[g][i][k];
-            }
-            M3 Rm;
-            lift6d(in[g][i], Rm);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) sR[f * LR + j * 9 + k] = Rm.a[k];
-        }
-        __syncthreads();
-        // B: chain, one subtree role per wave, lanes 0..31 = frames
-        {
-            const int lane = threadIdx.x & 63;
-            if (lane < nf) {
-                ChainLds io{sO, sR + lane * LR, sP + lane * LP};
-                fk_chain_role(threadIdx.x >> 6, io);
-            }
-        }
-        __syncthreads();
-        // C: out[(b0 + f) * T + t][0..n): n floats per frame, consecutive threads -> consecutive 16-byte pieces
+        // C (first part): out[(b0 + f) * T + t][0..n): n floats per frame, consecutive threads -> consecutive 16-byte pieces
         auto stream_out = [&](auto n_c, const float* lds, float* out) {
             constexpr int n = decltype(n_c)::value;        // compile-time: the division below is a multiply
             // 16-byte stores (a quarter of the store instructions; the four LDS reads per lane are 4-way bank conflicted,
@@ -1389,7 +1575,37 @@ __global__ __launch_bounds__(256) void decode_tail_fwd_kernel(const float* __res
                 }
             }
         };
-        if constexpr (C6) stream_out(std::integral_constant<int, NJ * 6>{}, s6, c6);
+        if constexpr (C6) {
+#pragma unroll
+            for (int i = 0; i < LIFTS; ++i) {
+                const int j = j0 + i * (256 / TF_FRAMES);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) s6[f * L6 + j * 6 + k] = in[g][i][k];
+            }
+            __syncthreads();
+            stream_out(std::integral_constant<int, NJ * 6>{}, s6, c6);
+            __syncthreads();                               // the 6D image is overwritten by the matrices
+        }
+        // A: lifts
+#pragma unroll
+        for (int i = 0; i < LIFTS; ++i) {
+            const int j = j0 + i * (256 / TF_FRAMES);
+            M3 Rm;
+            lift6d(in[g][i], Rm);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) sR[f * LR + j * 9 + k] = Rm.a[k];
+        }
+        __syncthreads();
+        // B: chain, one subtree role per wave, lanes 0..31 = frames
+        {
+            const int lane = threadIdx.x & 63;
+            if (lane < nf) {
+                ChainLds io{sO, sR + lane * LR, sP + lane * LP};
+                fk_chain_role(threadIdx.x >> 6, io);
+            }
+        }
+        __syncthreads();
+        // C: the matrices and the positions
         stream_out(std::integral_constant<int, NJ * 9>{}, sR, R);
         stream_out(std::integral_constant<int, NJ * 3>{}, sP, P);
         __syncthreads();                                   // the image is rewritten by the next group
@@ -1403,29 +1619,39 @@ static int tail_loss_launch(const float* dec_out, const float* gt6d, const float
                             float scale_rot, float scale_pos, float* d_dec_out, float* partial, int32_t* n_blocks_out,
                             hmvae_stream_t stream) {
     if (T <= 0 || T > 65535 || B <= 0 || bp < B || (bp & 63)) return HMVAE_ERR_ARG;
-    dim3 grid(bp / TL_FRAMES, T), block(256);
-    if (n_blocks_out) *n_blocks_out = (int32_t)(grid.x * grid.y);
-    if (!dec_out && !gt6d && !gtR && !gtP && !mask && !d_dec_out && !partial) return HMVAE_OK;      // size query
-    if (!dec_out || !gt6d || !gtR || !gtP || !offsets || !d_dec_out || !partial || (masked && !mask)) return HMVAE_ERR_ARG;
-    static int three_phase = -1;
+    static int three_phase = -1, fr3 = 0;
     if (three_phase < 0) {
         const char* e = getenv("HMVAE_TAIL3");       // "0": the joint-by-joint walk (round 1), kept for the A/B
         three_phase = (e && e[0] == '0') ? 0 : 1;
+        const char* f = getenv("HMVAE_TAIL3_FR");    // frames per workgroup of the three-phase kernel: 64 or 32
+        fr3 = (f && (atoi(f) == 64 || atoi(f) == 32)) ? atoi(f) : TL3_FR_DEFAULT;
     }
+    const int fr = three_phase ? fr3 : TL_FRAMES;
+    dim3 grid(bp / fr, T), block(256);
+    if (n_blocks_out) *n_blocks_out = (int32_t)(grid.x * grid.y);
+    if (!dec_out && !gt6d && !gtR && !gtP && !mask && !d_dec_out && !partial) return HMVAE_OK;      // size query
+    if (!dec_out || !gt6d || !gtR || !gtP || !offsets || !d_dec_out || !partial || (masked && !mask)) return HMVAE_ERR_ARG;
     if (three_phase) {
-        const size_t lds = sizeof(float) * (2 * TL_FRAMES * TL3_LR + 4 * 12 * TL_FRAMES + 16);
-        static bool attr[2] = {false, false};
-        const void* fn = masked ? (const void*)decode_tail_loss3_kernel<true> : (const void*)decode_tail_loss3_kernel<false>;
-        if (!attr[masked]) {
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return HMVAE_ERR_LAUNCH;
-            attr[masked] = true;
+        const size_t lds = sizeof(float) * ((size_t)fr * TL3_LR + 4 * 12 * fr + 16);      // 68 KB (64 frames) / 34 KB (32)
+        static bool attr[2][2] = {{false, false}, {false, false}};
+#define TL3_GO(MK_, FR_)                                                                                                   \
+    {                                                                                                                      \
+        if (!attr[MK_][FR_ == 64]) {                                                                                       \
+            if (hipFuncSetAttribute((const void*)decode_tail_loss3_kernel<MK_, FR_>,                                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)                  \
+                return HMVAE_ERR_LAUNCH;                                                                                   \
+            attr[MK_][FR_ == 64] = true;                                                                                   \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((decode_tail_loss3_kernel<MK_, FR_>), grid, block, lds, (hipStream_t)stream, dec_out, gt6d, gtR, \
+                           gtP, mask, offsets, T, B, bp, 2.f * scale_6d, 2.f * scale_rot, 2.f * scale_pos, d_dec_out,      \
+                           partial);                                                                                       \
+    }
+        if (masked) {
+            if (fr == 64) TL3_GO(true, 64) else TL3_GO(true, 32)
+        } else {
+            if (fr == 64) TL3_GO(false, 64) else TL3_GO(false, 32)
         }
-        if (masked)
-            hipLaunchKernelGGL(decode_tail_loss3_kernel<true>, grid, block, lds, (hipStream_t)stream, dec_out, gt6d, gtR, gtP, mask,
-                               offsets, T, B, bp, 2.f * scale_6d, 2.f * scale_rot, 2.f * scale_pos, d_dec_out, partial);
-        else
-            hipLaunchKernelGGL(decode_tail_loss3_kernel<false>, grid, block, lds, (hipStream_t)stream, dec_out, gt6d, gtR, gtP, mask,
-                               offsets, T, B, bp, 2.f * scale_6d, 2.f * scale_rot, 2.f * scale_pos, d_dec_out, partial);
+#undef TL3_GO
         return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
     }
     if (masked)

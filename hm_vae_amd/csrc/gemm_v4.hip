@@ -80,13 +80,11 @@ __device__ __forceinline__ unsigned chunk_swz(unsigned k) {
     return ((k >> 1) & 1u) | (((k >> 3) & 1u) << 1);
 }
 
-// PP > 1 (position blocks, hmvae_gemm4_desc.pp): the unit's PP output positions share the weight fragment of every step
-// (loaded and split once, multiplied PP times) and the activation images -- n_img of them in LDS, addressed by the
-// host-made schedule (planner.build_pp_schedule): a step stages at most one image (so the register ring is the one of
-// PP = 1) and names, per position, the image that holds its source rows; a row read by several (position, tap) pairs of
-// the block is staged once per 32 channels.
-template <int MTW, int NT, int R, int PP>
-__global__ __launch_bounds__(256, (PP == 4 && MTW == 2) ? 1 : 2) void gather_gemm4_kernel(hmvae_gemm4_desc d) {
+// (Position blocks -- units of 2 / 4 output positions sharing the weight fragment of every step and a scheduled set of
+// activation images -- were built in round 2, measured never faster than this plain form at 256 and 1 024 sequences per GPU
+// on any layer side, with four- and eight-wave workgroups alike, and removed in round 3: DESIGN.md 4.6 / EXPERIMENTS.md.)
+template <int MTW, int NT, int R>
+__global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d) {
     constexpr int NC = NT * 16;                  // columns of the unit
     constexpr int PITCH = NC * 2;                // bytes per image row
     constexpr unsigned PLB = 32 * PITCH;         // bytes per plane
@@ -98,9 +96,8 @@ __global__ __launch_bounds__(256, (PP == 4 && MTW == 2) ? 1 : 2) void gather_gem
     constexpr int RP = MTG * 16;
     constexpr int D = R - 1;                     // K steps in flight ahead of the one being multiplied
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    // layout: [image 0][image 1] (PP > 1: n_img images) [rows table: max_nc32*32 u32][items: max_items*2 int][flag]
-    const int n_img = PP == 1 ? 2 : d.n_img;
-    unsigned* lds_rows = (unsigned*)(lds + (unsigned)n_img * BUFB);
+    // layout: [image 0][image 1][rows table: max_nc32*32 u32][items: max_items*2 int][flag]
+    unsigned* lds_rows = (unsigned*)(lds + 2u * BUFB);
     int* lds_items = (int*)(lds_rows + V4_MAX_NC32 * 32);
     int* lds_flag = lds_items + 2 * V4_MAX_ITEMS;
 
@@ -114,11 +111,8 @@ __global__ __launch_bounds__(256, (PP == 4 && MTW == 2) ? 1 : 2) void gather_gem
     const int n_cb = d.bp / NC;
     const int cb = unit % n_cb;
     const int r0 = unit / n_cb;
-    const int pb = r0 % d.n_pos;                 // output position, or position block (PP > 1: n_pos counts the blocks)
+    const int pb = r0 % d.n_pos;                 // output position
     const int g = r0 / d.n_pos;
-    int ppos[PP];                                // output position of slot j, -1: none (wave-uniform)
-#pragma unroll
-    for (int j = 0; j < PP; ++j) ppos[j] = PP == 1 ? pb : d.blk_pos[pb * PP + j];
 
     STAMP4(0);
     const int tid = threadIdx.x;
@@ -130,22 +124,13 @@ __global__ __launch_bounds__(256, (PP == 4 && MTW == 2) ? 1 : 2) void gather_gem
     const int bp = d.bp;
     {
         const int* gi = d.items + 2 * d.pb_off[pb];
-        if (PP == 1) {
-            for (int i = tid; i < 2 * nitems; i += 256) lds_items[i] = (i & 1) ? (gi[i] & 0xff) : gi[i] * d.src_ts * bp * 4;
-        } else {                                 // word 0: byte offset of the row to stage (none: 0, and bit 28 of word 1)
-            for (int i = tid; i < nitems; i += 256) {
-                const int q = gi[2 * i], y = gi[2 * i + 1];
-                lds_items[2 * i] = q < 0 ? 0 : q * d.src_ts * bp * 4;
-                lds_items[2 * i + 1] = y | (q < 0 ? (1 << 28) : 0) | (i == 0 ? (1 << 29) : 0);      // bit 29: first step
-            }
-        }
+        for (int i = tid; i < 2 * nitems; i += 256) lds_items[i] = (i & 1) ? (gi[i] & 0xff) : gi[i] * d.src_ts * bp * 4;
         const int* gr = d.chan_rows + choff;
         for (int i = tid; i < 32 * nc32; i += 256) lds_rows[i] = (unsigned)gr[i] * (unsigned)bp * 4u;
     }
     const int nks = nc32 * nitems;
-    // K parts: any cut for PP = 1; whole 32-channel blocks for PP > 1 (the image schedule restarts with every block)
-    const int k0 = PP == 1 ? (int)((long long)nks * sp / S) : (int)((long long)nc32 * sp / S) * nitems;
-    const int k1 = PP == 1 ? (int)((long long)nks * (sp + 1) / S) : (int)((long long)nc32 * (sp + 1) / S) * nitems;
+    const int k0 = (int)((long long)nks * sp / S);                  // this part's K steps
+    const int k1 = (int)((long long)nks * (sp + 1) / S);
     const int ntiles = d.g_ntiles[g];
     const bool mine = wave * MTW < ntiles;                      // this wave owns at least one live row tile (wave-uniform)
 
@@ -168,13 +153,11 @@ __global__ __launch_bounds__(256, (PP == 4 && MTW == 2) ? 1 : 2) void gather_gem
     const unsigned lane_a = (unsigned)(wave * MTW) * 2048u + (unsigned)lane * 16u;
     const unsigned kt = (unsigned)d.kt;
 
-    f32x4 acc[PP][MTW][NT];
+    f32x4 acc[MTW][NT];
 #pragma unroll
-    for (int j = 0; j < PP; ++j)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[j][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();                                             // tables visible
     STAMP4(1);
@@ -186,7 +169,6 @@ __global__ __launch_bounds__(256, (PP == 4 && MTW == 2) ? 1 : 2) void gather_gem
     int c32 = k0 / (nitems > 0 ? nitems : 1), it = k0 - c32 * nitems, ks = k0;
     f32x4 rb[R][NPASS];
     f32x4 ra[R][MTW][2];                  // a row tile's A fragment: 8 consecutive channels of row m per lane, fp32
-    int ry[R];                            // PP > 1: the step's schedule word
     auto advance = [&]() {
         const bool more = ks + 1 < k1;
         const int ni = it + 1;
@@ -195,10 +177,8 @@ __global__ __launch_bounds__(256, (PP == 4 && MTW == 2) ? 1 : 2) void gather_gem
         c32 = more ? (wrap ? c32 + 1 : c32) : c32;
         ks = more ? ks + 1 : ks;
     };
-    auto fetch = [&](f32x4 (&b)[NPASS], f32x4 (&a)[MTW][2], int& yw, bool with_a) {
-        int2 item = *(const int2*)(lds_items + 2 * it);
-        yw = item.y;
-        if (PP > 1) item.y = (item.y & 0xff) == 0xff ? 0 : (item.y & 0xff);      // a step that only stages: any fragment
+    auto fetch = [&](f32x4 (&b)[NPASS], f32x4 (&a)[MTW][2], bool with_a) {
+        const int2 item = *(const int2*)(lds_items + 2 * it);
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const unsigned ro = lds_rows[c32 * 32 + kr + RPP * i];
@@ -224,9 +204,8 @@ __global__ __launch_bounds__(256, (PP == 4 && MTW == 2) ? 1 : 2) void gather_gem
             *(u32x2*)(img + 2 * PLB + st_off[i]) = (u32x2){h2a, h2b};
         }
     };
-    auto compute = [&](const char* img0, const f32x4 (&af)[MTW][2], int yw) {
+    auto compute = [&](const char* img, const f32x4 (&af)[MTW][2]) {
         typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
-        if (PP > 1 && (yw & 0xff) == 0xff) return;                      // (wave-uniform)
         // the weights' three planes are made here, in registers (44 vector instructions per tile and K step, beside
         // 24-96 MFMAs): 4 instead of 6 bytes per weight through the load path, and nothing for the pack to split
         bf16x8 a[MTW][3];
@@ -247,67 +226,48 @@ __global__ __launch_bounds__(256, (PP == 4 && MTW == 2) ? 1 : 2) void gather_gem
             a[mt][2] = __builtin_bit_cast(bf16x8, w2);
         }
 #pragma unroll
-        for (int j = 0; j < PP; ++j) {
-            const char* img = img0;
-            if (PP > 1) {
-                const int sl = (yw >> (12 + 4 * j)) & 0xf;               // the image that holds position j's rows
-                if (sl == 0xf) continue;                                 // (wave-uniform) the position sits this step out
-                img = lds + (unsigned)sl * BUFB;
+        for (int nt = 0; nt < NT; ++nt) {
+            bf16x8 b[3];
+            const unsigned ro = rd_base ^ ((unsigned)nt << 5);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + pl * PLB + ro));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + pl * PLB + 4 * PITCH + ro));
+                const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                b[pl] = __builtin_bit_cast(bf16x8, t);
             }
+            // smallest cross terms first: (0,2) (2,0) (1,1) | (0,1) (1,0) | (0,0)
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                bf16x8 b[3];
-                const unsigned ro = rd_base ^ ((unsigned)nt << 5);
+            for (int t = 0; t < 6; ++t)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + pl * PLB + ro));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + pl * PLB + 4 * PITCH + ro));
-                    const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    b[pl] = __builtin_bit_cast(bf16x8, t);
-                }
-                // smallest cross terms first: (0,2) (2,0) (1,1) | (0,1) (1,0) | (0,0)
-                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-#pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt) {
+                for (int mt = 0; mt < MTW; ++mt) {
 #ifdef V4_ABL_NOMFMA             // timing ablation (wrong results): the operands are consumed by one cheap instruction
-                        acc[j][mt][nt][0] += __builtin_bit_cast(f32x4, a[mt][PA[t]])[0] + __builtin_bit_cast(f32x4, b[PB[t]])[0];
+                    acc[mt][nt][0] += __builtin_bit_cast(f32x4, a[mt][PA[t]])[0] + __builtin_bit_cast(f32x4, b[PB[t]])[0];
 #else
-                        acc[j][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][PA[t]], b[PB[t]], acc[j][mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][PA[t]], b[PB[t]], acc[mt][nt], 0, 0, 0);
 #endif
-                    }
-            }
+                }
         }
-    };
-    // PP > 1: the step's image (named by the schedule) is written only if the step stages one
-    auto stash_pp = [&](const f32x4 (&b)[NPASS], int yw) {
-        // the schedule restarts with every 32-channel block and knows nothing of the images the previous block's last step
-        // multiplies with: nobody stages into them before everybody is past that step
-        if (yw & (1 << 29)) __syncthreads();
-        if (yw & (1 << 28)) return;                                     // (wave-uniform)
-        stash(lds + (unsigned)((yw >> 8) & 0xf) * BUFB, b);
     };
     const int n = k1 - k0;
     int cnt = 0;
     auto run = [&](auto MINE) {
         constexpr bool M = decltype(MINE)::value;
 #pragma unroll
-        for (int u = 0; u < D; ++u) fetch(rb[u], ra[u], ry[u], M);
+        for (int u = 0; u < D; ++u) fetch(rb[u], ra[u], M);
         const int trips = n / R;
         STAMP4(2);
         for (int t = 0; t < trips; ++t) {
 #pragma unroll
             for (int u = 0; u < R; ++u) {
                 char* img = lds + ((cnt & 1) ? BUFB : 0u);
-                const int yw = PP > 1 ? __builtin_amdgcn_readfirstlane(ry[u]) : 0;
-                if (PP > 1) stash_pp(rb[u], yw);
-                else stash(img, rb[u]);
+                stash(img, rb[u]);
 #ifndef V4_ABL_NOBAR             // timing ablation (wrong results): no workgroup barrier per K step
                 __syncthreads();
 #endif
-                fetch(rb[(u + D) % R], ra[(u + D) % R], ry[(u + D) % R], M);
-                if (M) compute(img, ra[u], yw);
+                fetch(rb[(u + D) % R], ra[(u + D) % R], M);
+                if (M) compute(img, ra[u]);
                 ++cnt;
             }
         }
@@ -316,11 +276,9 @@ __global__ __launch_bounds__(256, (PP == 4 && MTW == 2) ? 1 : 2) void gather_gem
         for (int u = 0; u < R - 1; ++u) {
             if (u < rem) {
                 char* img = lds + ((cnt & 1) ? BUFB : 0u);
-                const int yw = PP > 1 ? __builtin_amdgcn_readfirstlane(ry[u]) : 0;
-                if (PP > 1) stash_pp(rb[u], yw);
-                else stash(img, rb[u]);
+                stash(img, rb[u]);
                 __syncthreads();
-                if (M) compute(img, ra[u], yw);
+                if (M) compute(img, ra[u]);
                 ++cnt;
             }
         }
@@ -361,8 +319,8 @@ __global__ __launch_bounds__(256, (PP == 4 && MTW == 2) ? 1 : 2) void gather_gem
         }
         *(f32x4*)dp = s;
     };
-    // A position's tile leaves the registers through LDS (the images are free now: every wave is past its last read after
-    // the barrier) so that rows go out as 16-byte pieces: [row < RP][NC] floats; the positions of a block one after the other.
+    // The tile leaves the registers through LDS (the images are free now: every wave is past its last read after the
+    // barrier) so that rows go out as 16-byte pieces: [row < RP][NC] floats.
     // Split K, hand-off between workgroups inside the launch (the per-XCD L2s are not coherent with each other and a CU's
     // L1 is never refreshed): every byte of a part is stored write-through (sc1, 16 bytes per lane), every storing wave
     // drains its stores, the workgroup meets at a barrier, ONE lane adds to the unit's counter (agent scope); the workgroup
@@ -371,29 +329,25 @@ __global__ __launch_bounds__(256, (PP == 4 && MTW == 2) ? 1 : 2) void gather_gem
     const int live_rows = ntiles * 16;
     constexpr unsigned TILE_B = RP * NC * 4;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(d.scratch + (size_t)unit * S * (PP * RP * NC)), 0, S * PP * (int)TILE_B, 0x00020000);
-    const unsigned part_b = (unsigned)sp * (unsigned)PP * TILE_B;
+        (void*)(d.scratch + (size_t)unit * S * (RP * NC)), 0, S * (int)TILE_B, 0x00020000);
+    const unsigned part_b = (unsigned)sp * TILE_B;
+    __syncthreads();
+    if (mine) {
 #pragma unroll
-    for (int j = 0; j < PP; ++j) {
-        if (ppos[j] < 0) continue;                                   // (wave-uniform)
-        __syncthreads();
-        if (mine) {
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        tile[((wave * MTW + mt) * 16 + rq * 4 + r) * NC + nt * 16 + n_] = acc[j][mt][nt][r];
-        }
-        __syncthreads();
-        for (int idx = tid; idx < live_rows * CQ; idx += 256) {
-            const int row = idx / CQ, c4 = idx - row * CQ;
-            const f32x4 v = *(const f32x4*)(tile + row * NC + c4 * 4);
-            if (S == 1) finish(v, row, c4 * 4, ppos[j]);
-            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
-                                                        part_b + (unsigned)j * TILE_B + (unsigned)(row * NC + c4 * 4) * 4u, 0, 16);
-        }
+                for (int r = 0; r < 4; ++r)
+                    tile[((wave * MTW + mt) * 16 + rq * 4 + r) * NC + nt * 16 + n_] = acc[mt][nt][r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < live_rows * CQ; idx += 256) {
+        const int row = idx / CQ, c4 = idx - row * CQ;
+        const f32x4 v = *(const f32x4*)(tile + row * NC + c4 * 4);
+        if (S == 1) finish(v, row, c4 * 4, pb);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                    part_b + (unsigned)(row * NC + c4 * 4) * 4u, 0, 16);
     }
     if (S == 1) {
         STAMP4(6);
@@ -406,17 +360,13 @@ __global__ __launch_bounds__(256, (PP == 4 && MTW == 2) ? 1 : 2) void gather_gem
     __syncthreads();
     STAMP4(5);
     if (*lds_flag != S - 1) return;
-#pragma unroll
-    for (int j = 0; j < PP; ++j) {
-        if (ppos[j] < 0) continue;
-        for (int idx = tid; idx < live_rows * CQ; idx += 256) {
-            const int row = idx / CQ, c4 = idx - row * CQ;
-            const unsigned off = (unsigned)j * TILE_B + (unsigned)(row * NC + c4 * 4) * 4u;
-            f32x4 s = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
-            for (int i = 1; i < S; ++i)
-                s += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)i * (unsigned)PP * TILE_B, 0, 16));
-            finish(s, row, c4 * 4, ppos[j]);
-        }
+    for (int idx = tid; idx < live_rows * CQ; idx += 256) {
+        const int row = idx / CQ, c4 = idx - row * CQ;
+        const unsigned off = (unsigned)(row * NC + c4 * 4) * 4u;
+        f32x4 s = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+        for (int i = 1; i < S; ++i)
+            s += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)i * TILE_B, 0, 16));
+        finish(s, row, c4 * 4, pb);
     }
     if (tid == 0) __hip_atomic_store(d.counters + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left as found
     STAMP4(6);
@@ -566,29 +516,27 @@ __global__ __launch_bounds__(256) void pack4_kernel(const hmvae_pack_op* __restr
     }
 }
 
-template <int MTW, int NT, int PP>
+template <int MTW, int NT>
 int launch4(const hmvae_gemm4_desc* d, hipStream_t s) {
     // K steps in flight per wave: enough to cover ~2 us of load latency with the MFMA time of a step (96 cycles per tile
-    // pair and position), within the registers the accumulators (PP * MTW * NT tiles) leave
-    constexpr int W = PP * MTW * NT;
-    constexpr int R = PP == 1 ? (W <= 4 ? V4_R14 : (W <= 8 ? 4 : 3))
-                              : (W <= 8 ? 6 : (W <= 16 ? ((MTW == 1 && NT == 4) ? 6 : 4) : 3));
+    // pair), within the registers the accumulators (MTW * NT tiles) leave
+    constexpr int W = MTW * NT;
+    constexpr int R = W <= 4 ? V4_R14 : (W <= 8 ? 4 : 3);
     constexpr int NC = NT * 16;
-    const int n_img = PP == 1 ? 2 : d->n_img;
-    size_t lds = (size_t)n_img * 3 * 32 * NC * 2 + V4_MAX_NC32 * 32 * 4 + 2 * V4_MAX_ITEMS * 4 + 16;
+    size_t lds = (size_t)2 * 3 * 32 * NC * 2 + V4_MAX_NC32 * 32 * 4 + 2 * V4_MAX_ITEMS * 4 + 16;
     const size_t tile = (size_t)MTW * 64 * NC * 4;
     if (tile > lds) lds = tile;
     if (lds > 160 * 1024) return HMVAE_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gather_gemm4_kernel<MTW, NT, R, PP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)gather_gemm4_kernel<MTW, NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return HMVAE_ERR_LAUNCH;
         attr_set = true;
     }
     const int n_wg = d->n_units * d->n_split;
     const int per = (n_wg + 7) / 8;
-    hipLaunchKernelGGL((gather_gemm4_kernel<MTW, NT, R, PP>), dim3((unsigned)(per * 8)), dim3(256), lds, s, *d);
+    hipLaunchKernelGGL((gather_gemm4_kernel<MTW, NT, R>), dim3((unsigned)(per * 8)), dim3(256), lds, s, *d);
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }
 
@@ -606,20 +554,13 @@ extern "C" int hmvae_gather_gemm_v4(const hmvae_gemm4_desc* d, hmvae_stream_t st
     if (d->max_items <= 0 || d->max_items > V4_MAX_ITEMS || d->max_nc32 <= 0 || d->max_nc32 > V4_MAX_NC32)
         return HMVAE_ERR_UNSUPPORTED;
     if ((long long)d->n_groups * d->n_pos * (d->bp / d->nc) != d->n_units) return HMVAE_ERR_ARG;
-    const int pp = d->pp > 1 ? d->pp : 1;
-    if (pp > 1 && (!d->blk_pos || d->n_img < 2 || d->n_img > 15)) return HMVAE_ERR_ARG;
+    if (d->pp > 1) return HMVAE_ERR_UNSUPPORTED;         // position blocks: removed in round 3 (never faster), field reserved
     hipStream_t s = (hipStream_t)stream;
-    const int key = pp * 10000 + d->mtw * 1000 + d->nc;
-    switch (key) {
-        case 11064: return launch4<1, 4, 1>(d, s);
-        case 11128: return launch4<1, 8, 1>(d, s);
-        case 12064: return launch4<2, 4, 1>(d, s);
-        case 12128: return launch4<2, 8, 1>(d, s);
-        case 21064: return launch4<1, 4, 2>(d, s);
-        case 21128: return launch4<1, 8, 2>(d, s);
-        case 22064: return launch4<2, 4, 2>(d, s);
-        case 41064: return launch4<1, 4, 4>(d, s);
-        case 42064: return launch4<2, 4, 4>(d, s);
+    switch (d->mtw * 1000 + d->nc) {
+        case 1064: return launch4<1, 4>(d, s);
+        case 1128: return launch4<1, 8>(d, s);
+        case 2064: return launch4<2, 4>(d, s);
+        case 2128: return launch4<2, 8>(d, s);
         default: return HMVAE_ERR_UNSUPPORTED;
     }
 }

@@ -24,10 +24,6 @@ USE_V3 = _os.environ.get("HMVAE_V3", "1") != "0"
 # results.  "auto" (default): timed per layer side and batch size against the v2 / v3 pick; "0" never; "1" wherever the
 # kernel supports the problem (first candidate shape).
 USE_V4 = _os.environ.get("HMVAE_V4", "auto")
-# position blocks of the v4 kernel (hmvae_gemm4_desc.pp): candidates of the autotuner only with HMVAE_V4_PP=1 -- measured
-# at 256 and 1024 sequences per GPU no layer side of the shipped configs is faster with them, and every
-# candidate costs tuning time
-USE_V4_PP = _os.environ.get("HMVAE_V4_PP", "0") == "1"
 # Let the autotuner consider the persistent (stream-K) weight-gradient launch.  Off by default: timed alone it wins on
 # most layers, but in the step these GEMMs share the chip with the data-gradient chain and with each other, and workers
 # that hold every CU for their whole launch cost the neighbours more than the balanced tail saves.  A/B on the whole step,
@@ -167,7 +163,6 @@ class _Side:
         self._tuning = False                  # a new batch size is being tuned: the fp32 layout must be current (autotune)
         self._act_now = None
         self._act_tabs = {}
-        self._pp_plans = {}
         # fold = dict(taps [kt][nf], coefs [kt][nf], kt_real, child_tab [n][4] or None, child_side): the packed matrix is a
         # composite one (virtual taps, merged channels; hmvae.h, hmvae_pack_op)
         self.fold = None
@@ -484,63 +479,37 @@ class _Side:
         self._autotune_v4(src, dst, bp, bias, flags, slope)
 
     # -- fourth generation (bf16 planes) --
-    V4_PP_SHAPES = {1: ((2, 128), (2, 64), (1, 128), (1, 64)), 2: ((2, 64), (1, 128), (1, 64)), 4: ((2, 64), (1, 64))}
+    V4_SHAPES = ((2, 128), (2, 64), (1, 128), (1, 64))       # (row tiles per wave, columns per unit) of the v4 launch
 
-    def pp_plan(self, pp):
-        """Device tables of the position-block schedule (planner.build_pp_schedule) for blocks of `pp` positions, or None."""
-        if pp not in self._pp_plans:
-            sc = P.build_pp_schedule(self.pairs_host, pp) if pp > 1 else None
-            if sc is not None:
-                sc = dict(sc, blk_pos_dev=_dev(sc["blk_pos"].reshape(-1), self.device), blk_off_dev=_dev(sc["blk_off"], self.device),
-                          blk_len_dev=_dev(sc["blk_len"], self.device), items_dev=_dev(sc["items"].reshape(-1), self.device),
-                          n_blk=len(sc["blk_off"]), max_items=int(sc["blk_len"].max()))
-            self._pp_plans[pp] = sc
-        return self._pp_plans[pp]
-
-    def v4_blocks(self, pp):
-        return self.n_pos if pp == 1 else self.pp_plan(pp)["n_blk"]
-
-    def v4_splits(self, bp, nc, pp=1):
-        """K splits of the v4 launch worth timing: enough workgroups to fill the chip, at least two K steps per part
-        (position blocks: parts are whole 32-channel blocks)."""
+    def v4_splits(self, bp, nc):
+        """K splits of the v4 launch worth timing: enough workgroups to fill the chip, at least two K steps per part."""
         g = self.g
-        n_units = g.n_groups * self.v4_blocks(pp) * (int(bp) // nc)
-        if pp == 1:
-            nks_min = int((g.g_nc4 // 8).min()) * max(1, min(len(l) for l in self.pairs_host))
-            cand = [c for c in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16) if c <= max(1, nks_min // 2) and n_units * c <= 4096]
-        else:
-            cand = [c for c in (1, 2, 3, 4, 5, 6, 8) if c <= int((g.g_nc4 // 8).min()) and n_units * c <= 4096]
+        n_units = g.n_groups * self.n_pos * (int(bp) // nc)
+        nks_min = int((g.g_nc4 // 8).min()) * max(1, min(len(l) for l in self.pairs_host))
+        cand = [c for c in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16) if c <= max(1, nks_min // 2) and n_units * c <= 4096]
         cand = cand or [1]
         big = [c for c in cand if n_units * c >= 192]
         return (big[:6] if big else cand[-2:])
 
-    def _v4_buffers(self, bp, nc, split, pp=1):
-        key = (int(bp), int(nc), int(split), int(pp))
+    def _v4_buffers(self, bp, nc, split):
+        key = (int(bp), int(nc), int(split))
         if key not in self._v4_scratch:
             if torch.cuda.is_current_stream_capturing():
                 raise _lib.HmvaeError("v4 gather-GEMM: scratch for a new launch shape during a stream capture")
             g = self.g
-            n_units = g.n_groups * self.v4_blocks(pp) * (int(bp) // nc)
-            self._v4_scratch[key] = (torch.empty(n_units * split * pp * g.mt * 16 * nc, dtype=torch.float32, device=self.device),
+            n_units = g.n_groups * self.n_pos * (int(bp) // nc)
+            self._v4_scratch[key] = (torch.empty(n_units * split * g.mt * 16 * nc, dtype=torch.float32, device=self.device),
                                      torch.zeros(n_units, dtype=torch.int32, device=self.device))
         return self._v4_scratch[key]
 
-    def run_v4(self, src, dst, bp, bias, flags, slope, nc, split, pp=1):
+    def run_v4(self, src, dst, bp, bias, flags, slope, nc, split):
         assert self.layout == 4
         g = self.g
-        if pp > 1:
-            sc = self.pp_plan(pp)
-            if sc is None:
-                raise _lib.HmvaeError("v4 gather-GEMM: no position-block schedule for pp = %d" % pp)
-            pb_off, pb_len, items, n_pblk, max_items = sc["blk_off_dev"], sc["blk_len_dev"], sc["items_dev"], sc["n_blk"], sc["max_items"]
-            blk_pos, n_img = sc["blk_pos_dev"], sc["n_img"]
-        else:
-            pb_off, pb_len, items, n_pblk, max_items = self.items_for(1)
-            blk_pos, n_img = None, 0
+        pb_off, pb_len, items, n_pblk, max_items = self.items_for(1)
         n_units = g.n_groups * n_pblk * (int(bp) // nc)
         scratch = counters = None
         if split > 1:
-            scratch, counters = self._v4_buffers(bp, nc, split, pp)
+            scratch, counters = self._v4_buffers(bp, nc, split)
         d = _lib.Gemm4Desc(_lib.ptr(src), _lib.ptr(dst), self.wp.data_ptr(), _lib.ptr(bias), _lib.ptr(self.bias_idx),
                            _lib.ptr(self.bias_idx2), _lib.ptr(self.g_nc32), _lib.ptr(self.g_woff4), _lib.ptr(self.g_choff),
                            _lib.ptr(self.g_ntiles), _lib.ptr(self.chan_rows), _lib.ptr(self.dst_rows), _lib.ptr(pb_off),
@@ -548,7 +517,7 @@ class _Side:
                            int(nc), g.kt, n_pblk, int(bp), int(split), n_units, max_items, int(g.g_nc4.max()) // 8,
                            self.src_ts, self.dst_ts, int(flags), float(slope), _lib.ptr(DEBUG_BUF),
                            *((_lib.ptr(self._act_now[0]), _lib.ptr(self._act_now[1])) if self._act_now else (None, None)),
-                           _lib.ptr(blk_pos), int(pp), int(n_img))
+                           None, 0, 0)                       # (reserved: the position-block fields, removed in round 3)
         _lib.check(_lib.load().hmvae_gather_gemm_v4(C.byref(d), _lib.stream()), "gather_gemm_v4")
 
     def _run_incumbent(self, src, dst, bp, bias, flags, slope):
@@ -572,12 +541,9 @@ class _Side:
                 sd = self.v4_side(int(hit[0]))
                 if sd is not None:
                     MultiPack(self.device).run([(sd, self._last_dense)])
-                    pp = int(hit[3]) if len(hit) > 3 else 1
-                    if pp > 1 and (not USE_V4_PP or sd.pp_plan(pp) is None):
-                        pp = 1
                     if int(hit[2]) > 1:
-                        sd._v4_buffers(bp, int(hit[1]), int(hit[2]), pp)
-                    self._tuned_v4[bp] = (int(hit[0]), int(hit[1]), int(hit[2]), pp)
+                        sd._v4_buffers(bp, int(hit[1]), int(hit[2]))
+                    self._tuned_v4[bp] = (int(hit[0]), int(hit[1]), int(hit[2]))
                     MultiPack.refresh(self)
             return
         scratch = torch.empty_like(dst)
@@ -590,16 +556,13 @@ class _Side:
             if sd is None:
                 continue
             MultiPack(self.device).run([(sd, self._last_dense)])
-            for pp in ((1, 2, 4) if USE_V4_PP else (1,)):
-                if pp > 1 and sd.pp_plan(pp) is None:
+            for nc in (128, 64):
+                if int(bp) % nc or (mtw, nc) not in self.V4_SHAPES:
                     continue
-                for nc in (128, 64):
-                    if int(bp) % nc or (mtw, nc) not in self.V4_PP_SHAPES[pp]:
-                        continue
-                    for sp in sd.v4_splits(bp, nc, pp):
-                        t = self._time(lambda: sd.run_v4(src, scratch, bp, bias, fl, slope, nc, sp, pp))
-                        if t < best[0]:
-                            best = (t, (mtw, nc, sp, pp))
+                for sp in sd.v4_splits(bp, nc):
+                    t = self._time(lambda: sd.run_v4(src, scratch, bp, bias, fl, slope, nc, sp))
+                    if t < best[0]:
+                        best = (t, (mtw, nc, sp))
         pick = best[1]
         for mtw in list(self.v4):
             sd = self.v4[mtw]
@@ -645,7 +608,7 @@ class _Side:
                 sd._act_now = (act, sd._act_table(act_base))
                 flags = int(flags) | _lib.FLAG_LEAKY_GRAD
             try:
-                sd.run_v4(src, dst, bp, bias, flags, slope, p4[1], p4[2], p4[3] if len(p4) > 3 else 1)
+                sd.run_v4(src, dst, bp, bias, flags, slope, p4[1], p4[2])
             finally:
                 sd._act_now = None
             return act is not None

@@ -435,58 +435,6 @@ def _pp_slots(steps, pp, n_img):
     return out
 
 
-def build_pp_schedule(pairs, pp, max_img=8):
-    """Position blocks for hmvae_gather_gemm_v4 (hmvae_gemm4_desc.pp): `pp` output positions share every weight fragment
-    of a step, and an activation image staged once serves every (position, tap) that reads its source position (for a
-    stride-1 convolution: kt + pp - 1 images per 32 channels instead of pp * kt).
-
-    Returns dict(pp, n_img, blk_pos [n_blk][pp] (-1: no position), blk_off, blk_len, items [n][2] int32 -- word 0 the source
-    position to stage (-1: none), word 1 = tap | load image << 8 | image of position j << (12 + 4j) (0xf: position j sits the
-    step out; tap 0xff: nobody multiplies) --, work = multiplying (step, position) pairs, steps = emitted steps in total) or
-    None.  The positions of a block are `pstep` apart (1, or 2 where neighbouring positions use disjoint taps: transposed
-    stride-2 convolutions, the phases of a folded x2 upsample); the choice with fewer steps wins."""
-    n_pos = len(pairs)
-    assert 1 <= pp <= 4
-    best = None
-    for pstep in ((1,) if pp == 1 else (1, 2)):
-        blocks = _pp_blocks(n_pos, pp, pstep)
-        merged = [_pp_merge(pairs, b) for b in blocks]
-        n_steps = sum(len(m) for m in merged)
-        if best is None or n_steps < best[0]:
-            best = (n_steps, blocks, merged)
-    _, blocks, merged = best
-    # images: the fewest whose schedule is within 3 % of the shortest one found (each image is 12-24 KB of LDS)
-    tried = []
-    for n_img in range(2 if pp == 1 else pp + 1, max_img + 1):
-        sc = [_pp_slots(m, pp, n_img) for m in merged]
-        if all(x is not None for x in sc):
-            tried.append((sum(len(x) for x in sc), n_img, sc))
-            if pp == 1:
-                break
-    if not tried:
-        return None
-    shortest = min(t[0] for t in tried)
-    _, n_img, sched = next(t for t in tried if t[0] <= 1.03 * shortest)
-    blk_pos = np.full((len(blocks), pp), -1, dtype=np.int32)
-    blk_off, blk_len, flat = [], [], []
-    work = 0
-    for bi, (b, sc) in enumerate(zip(blocks, sched)):
-        blk_pos[bi, :len(b)] = b
-        blk_off.append(len(flat))
-        blk_len.append(len(sc))
-        for tap, lq, ls, slots in sc:
-            word = (tap & 0xff) | (ls << 8)
-            for j in range(4):
-                word |= (slots[j] & 0xf) << (12 + 4 * j)
-            flat.append((lq, word))
-            work += sum(1 for x in slots if x != 0xf) if tap != 0xff else 0
-    if max(blk_len) > 256:
-        return None
-    return dict(pp=pp, n_img=n_img, blk_pos=blk_pos, blk_off=np.asarray(blk_off, dtype=np.int32),
-                blk_len=np.asarray(blk_len, dtype=np.int32), items=np.asarray(flat, dtype=np.int32).reshape(-1, 2),
-                work=work, steps=int(sum(blk_len)))
-
-
 def pick_np_ksplit(mt, n_groups, n_pos, n_col_tiles, avg_nc4, target_waves=2048):
     """(64-column units per wave, K split over the waves of a workgroup) for the gather-GEMM.
 

@@ -206,14 +206,9 @@ typedef struct {
     uint64_t* debug;         /* NULL in production; a diagnostic build (-DHMVAE_STAMP) writes 8 s_memtime stamps per workgroup */
     const float* act;        /* HMVAE_FLAG_LEAKY_GRAD, as in hmvae_gemm2_desc */
     const int32_t* act_rows;
-    /* Position blocks (pp = 2 | 4; 0 / 1: none): a unit is (group, BLOCK of pp output positions, column block).  The
-     * block's positions share the weight fragment of every step (loaded and split once, multiplied pp times) and the
-     * activation images: n_img of them live in LDS and a source row that several (position, tap) pairs of the block read
-     * is staged once per 32 channels.  n_pos then counts the blocks, pb_off / pb_len index them, blk_pos[block][pp] holds
-     * the output positions (-1: none) and an item is the schedule step the planner made (planner.build_pp_schedule):
-     * word 0 = source position to stage (-1: none), word 1 = tap | image to stage into << 8 | image of position j <<
-     * (12 + 4j) (0xf: position j sits the step out; tap 0xff: the step only stages).  K parts are whole 32-channel blocks;
-     * scratch is [n_units][n_split][pp][mtg*16][nc]. */
+    /* Reserved (round 2's position blocks -- units of 2 / 4 output positions sharing weight fragments and scheduled activation
+     * images -- were measured never faster than the plain launch and removed in round 3): NULL, 0, 0.  pp > 1 is refused with
+     * HMVAE_ERR_UNSUPPORTED. */
     const int32_t* blk_pos;
     int32_t pp, n_img;
 } hmvae_gemm4_desc;

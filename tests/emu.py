@@ -180,79 +180,6 @@ def emu_pack4(side, dense):
     return out
 
 
-def emu_gather4_pp(side, wp4, src, dst, pp, nc=64, split=1, bias=None, leaky=False, accum=False, slope=0.2):
-    """hmvae_gather_gemm_v4 with position blocks (hmvae_gemm4_desc.pp) on numpy operands: units (group, block of pp positions,
-    nc columns); per 32-channel block the schedule of planner.build_pp_schedule is walked step by step -- stage at most one
-    image, multiply every position of the block with the image the step names for it -- with the LDS images as a dict, and
-    the parts (whole 32-channel blocks) are summed in part order."""
-    g = side.g
-    mtg = g.mt
-    R = mtg * 16
-    sc = side.pp_plan(pp)
-    assert sc is not None
-    chan_rows, dst_rows = _np(side.chan_rows), _np(side.dst_rows)
-    bias_idx = _np(side.bias_idx)
-    bias_idx2 = None if getattr(side, "bias_idx2", None) is None else _np(side.bias_idx2)
-    woff4, ntiles = _np(side.g_woff4), _np(side.g_ntiles)
-    bp = src.shape[1]
-    done = set()
-    for gi in range(g.n_groups):
-        nc32 = int(g.g_nc4[gi]) // 8
-        rows_src = chan_rows[g.g_choff[gi]:g.g_choff[gi] + nc32 * 32]
-        for bi in range(len(sc["blk_off"])):
-            its = sc["items"][sc["blk_off"][bi]:sc["blk_off"][bi] + sc["blk_len"][bi]]
-            for cb in range(bp // nc):
-                cols = slice(cb * nc, (cb + 1) * nc)
-                total = np.zeros((pp, R, nc), dtype=np.float64)
-                for sp in range(split):
-                    part = np.zeros((pp, R, nc), dtype=np.float64)
-                    for c32 in range(nc32 * sp // split, nc32 * (sp + 1) // split):
-                        img, prev = {}, set()
-                        for lq, w in its:
-                            tap, ls = int(w) & 0xff, (int(w) >> 8) & 0xf
-                            if lq >= 0:
-                                assert ls not in prev                     # the previous step may still be multiplying with it
-                                img[ls] = src[rows_src[c32 * 32:(c32 + 1) * 32] + int(lq) * side.src_ts][:, cols].astype(np.float64)
-                            prev = set()
-                            if tap == 0xff:
-                                continue
-                            A = []
-                            for tile in range(int(ntiles[gi])):
-                                frag = wp4[int(woff4[gi]) // 2 + (c32 * g.kt + tap) * mtg + tile]
-                                frag = np.ascontiguousarray(frag.transpose(1, 0, 2)).reshape(64, 8)
-                                a = sum(bf16_value(pl) for pl in bf16_split3(frag))
-                                A.append(a.reshape(4, 16, 8).transpose(1, 0, 2).reshape(16, 32))
-                            for j in range(pp):
-                                sl = (int(w) >> (12 + 4 * j)) & 0xf
-                                if sl == 0xf:
-                                    continue
-                                prev.add(sl)
-                                for tile in range(int(ntiles[gi])):
-                                    part[j, tile * 16:(tile + 1) * 16] += A[tile] @ img[sl]
-                    total += part
-                for j in range(pp):
-                    pos = int(sc["blk_pos"][bi, j])
-                    if pos < 0:
-                        continue
-                    done.add(pos)
-                    for r in range(int(ntiles[gi]) * 16):
-                        dr = dst_rows[gi * R + r]
-                        if dr < 0:
-                            continue
-                        v = total[j, r]
-                        if bias is not None and bias_idx[gi * R + r] >= 0:
-                            bv = bias[bias_idx[gi * R + r]]
-                            if bias_idx2 is not None and bias_idx2[gi * R + r] >= 0:
-                                bv = 0.5 * (bv + bias[bias_idx2[gi * R + r]])
-                            v = v + bv
-                        if leaky:
-                            v = np.where(v > 0, v, v * slope)
-                        row = dr + pos * side.dst_ts
-                        dst[row, cols] = (dst[row, cols] + v) if accum else v
-    assert done == set(range(side.n_pos))
-    return dst
-
-
 def emu_gather4(side, wp4, src, dst, nc=64, split=1, bias=None, leaky=False, accum=False, slope=0.2):
     """hmvae_gather_gemm_v4 on numpy [rows, bp] operands (wp4 from emu_pack4): units (group, position, nc columns), K steps (c32, item) with the
     item fastest, cut into `split` parts that are summed in part order."""

@@ -78,15 +78,7 @@ def v4_variants(side, bp):
             continue
         for nc in (64, 128):
             if bp % nc == 0:
-                out.extend((sd, nc, sp, 1) for sp in (1, 3))
-        # position blocks (hmvae_gemm4_desc.pp): 2 / 4 output positions per unit, weight fragments shared, activation images
-        # scheduled by the planner; unsplit and split over whole 32-channel blocks
-        for pp in (2, 4):
-            if sd.pp_plan(pp) is None:
-                continue
-            for nc in (64, 128):
-                if bp % nc == 0 and (mtw, nc) in sd.V4_PP_SHAPES[pp]:
-                    out.extend((sd, nc, sp, pp) for sp in sorted(set((1, min(2, int(sd.g.g_nc4.min()) // 8)))))
+                out.extend((sd, nc, sp) for sp in (1, 3))
     return out
 
 
@@ -96,18 +88,18 @@ def check_v4(side, dense, src, bp, bias, flags, ref, read_back, what):
     var = v4_variants(side, bp)
     assert var, what
     packed = set()
-    for sd, nc, sp, pp in var:
+    for sd, nc, sp in var:
         if id(sd) not in packed:
             ops.MultiPack(src.device).run([(sd, dense)])
             packed.add(id(sd))
         out = torch.full((read_back[0], bp), float("nan"), device=src.device)
-        sd.run_v4(src, out, bp, bias, flags, 0.2, nc, sp, pp)
-        assert rel_err(read_back[1](out), ref) < TOL, (what, sd.g.mt, nc, sp, pp)
+        sd.run_v4(src, out, bp, bias, flags, 0.2, nc, sp)
+        assert rel_err(read_back[1](out), ref) < TOL, (what, sd.g.mt, nc, sp)
         if sp > 1 and not (flags & _lib.FLAG_LEAKY):
-            sd.run_v4(src, out, bp, bias, flags | _lib.FLAG_ACCUM, 0.2, nc, sp, pp)
-            assert rel_err(read_back[1](out), 2 * ref) < TOL, (what, "accumulate", sd.g.mt, nc, sp, pp)
-            sd.run_v4(src, out, bp, bias, flags, 0.2, nc, sp, pp)           # counters were left at zero: a third launch agrees
-            assert rel_err(read_back[1](out), ref) < TOL, (what, "relaunch", sd.g.mt, nc, sp, pp)
+            sd.run_v4(src, out, bp, bias, flags | _lib.FLAG_ACCUM, 0.2, nc, sp)
+            assert rel_err(read_back[1](out), 2 * ref) < TOL, (what, "accumulate", sd.g.mt, nc, sp)
+            sd.run_v4(src, out, bp, bias, flags, 0.2, nc, sp)           # counters were left at zero: a third launch agrees
+            assert rel_err(read_back[1](out), ref) < TOL, (what, "relaunch", sd.g.mt, nc, sp)
 
 
 CONV_CASES = [
@@ -209,9 +201,9 @@ def test_skeleton_conv_fwd_bwd(dev, case):
     ops.leaky_bwd(plain, act, want, want.numel())
     want_map = torch.where(exempt, plain, want)
     sides = [(op.bwd, lambda sd, o, fl: sd.run_v2(gys, o, bp, None, fl, 0.2))]
-    for sd4, nc, sp, pp in v4_variants(op.bwd, bp):
+    for sd4, nc, sp in v4_variants(op.bwd, bp):
         ops.MultiPack(dev).run([(sd4, wd_poison)])
-        sides.append((sd4, lambda sd, o, fl, nc=nc, sp=sp, pp=pp: sd.run_v4(gys, o, bp, None, fl, 0.2, nc, sp, pp), (nc, sp, pp)))
+        sides.append((sd4, lambda sd, o, fl, nc=nc, sp=sp: sd.run_v4(gys, o, bp, None, fl, 0.2, nc, sp), (nc, sp)))
     sides[0] = sides[0] + ("v2",)
     for sd, launch, shape in sides:
         ref_plain = torch.empty_like(dxs)

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 from oracle import hmvae_oracle as O
 from hm_vae_amd import ops, planner, topology
 from hm_vae_amd import planner as P
-from emu import emu_pack, emu_gather, emu_wgrad, emu_pack4, emu_gather4, emu_gather4_pp
+from emu import emu_pack, emu_gather, emu_wgrad, emu_pack4, emu_gather4
 from helpers import rel_err
 
 
@@ -30,15 +30,6 @@ def check_v4_tables(side, dense, src, ref_soa_fn, ref, n_rows, bias=None, leaky=
             emu_gather4(sd, wp4, src, out, nc=64, split=split, bias=bias, leaky=leaky)
             assert rel_err(ref_soa_fn(out), ref) < 1e-5, (mtw, split)
             n += 1
-        # position blocks: the planner's image schedules (2 and 4 positions per unit), walked step by step
-        for pp in (2, 4):
-            sc = sd.pp_plan(pp)
-            if sc is None or mtw == 2 and pp == 4:
-                continue
-            assert sc["n_img"] <= 8 and sc["steps"] <= sum(len(l) for l in sd.pairs_host)
-            out = np.zeros((n_rows, src.shape[1]), dtype=np.float32)
-            emu_gather4_pp(sd, wp4, src, out, pp, nc=64, split=min(2, int(g.g_nc4.min()) // 8), bias=bias, leaky=leaky)
-            assert rel_err(ref_soa_fn(out), ref) < 1e-5, (mtw, "pp", pp)
     assert n > 0
 
 

@@ -58,25 +58,21 @@ for name, op in zip(names, convs):
             g4 = sd.g
             issued4 = 2.0 * (g4.g_nc4 * 4).sum() * 16 * g4.mt * n_items * bp      # as if every tile of a group were live
             live = 2.0 * sum(int(nc4) * 4 * 16 * int(nt) for nc4, nt in zip(g4.g_nc4, sd.g_ntiles.cpu().numpy())) * n_items * bp
-            for pp in (1, 2, 4):
-                if pp > 1 and sd.pp_plan(pp) is None:
-                    continue
-                for nc in (128, 64):
-                    if bp % nc or (mtw, nc) not in sd.V4_PP_SHAPES[pp]: continue
-                    res = []
-                    for sp in sd.v4_splits(bp, nc, pp):
-                        t4 = timeit(lambda: sd.run_v4(src, dst, bp, None, 0, 0.2, nc, sp, pp), reps=8)
-                        res.append((sp, t4))
-                        if best is None or t4 < best[0]:
-                            best = (t4, mtw, nc, sp, pp)
-                        if pp == 1 and (best1 is None or t4 < best1):
-                            best1 = t4
-                    extra = "" if pp == 1 else " (images %d, steps %d of %d)" % (sd.pp_plan(pp)["n_img"], sd.pp_plan(pp)["steps"], n_items)
-                    print("   v4 mtw %d pp %d nc %3d groups %3d wgs/split %4d live-tile flops %5.2f G: %s%s" % (
-                        mtw, pp, nc, g4.n_groups, g4.n_groups * sd.v4_blocks(pp) * (bp // nc), live / 1e9,
-                        "  ".join("S%d %.1f" % r for r in res), extra), flush=True)
+            for nc in (128, 64):
+                if bp % nc or (mtw, nc) not in sd.V4_SHAPES: continue
+                res = []
+                for sp in sd.v4_splits(bp, nc):
+                    t4 = timeit(lambda: sd.run_v4(src, dst, bp, None, 0, 0.2, nc, sp), reps=8)
+                    res.append((sp, t4))
+                    if best is None or t4 < best[0]:
+                        best = (t4, mtw, nc, sp)
+                    if best1 is None or t4 < best1:
+                        best1 = t4
+                print("   v4 mtw %d nc %3d groups %3d wgs/split %4d live-tile flops %5.2f G: %s" % (
+                    mtw, nc, g4.n_groups, g4.n_groups * sd.n_pos * (bp // nc), live / 1e9,
+                    "  ".join("S%d %.1f" % r for r in res)), flush=True)
         if best is None:
             continue
-        print("   best v4 %s: %.1f us (pp 1: %.1f) vs v2 %.1f us  (x%.2f)" % (best[1:], best[0], best1, t2, t2 / best[0]), flush=True)
+        print("   best v4 %s: %.1f us vs v2 %.1f us  (x%.2f)" % (best[1:], best[0], t2, t2 / best[0]), flush=True)
         tot2 += t2; tot4 += min(t2, best[0]); tot41 += min(t2, best1)
-print("sum v2 %.1f us, sum min(v2, v4 without position blocks) %.1f us, sum min(v2, v4) %.1f us" % (tot2, tot41, tot4))
+print("sum v2 %.1f us, sum min(v2, v4) %.1f us" % (tot2, tot4))
