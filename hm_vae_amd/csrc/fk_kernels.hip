@@ -361,6 +361,9 @@ __device__ __forceinline__ void fk_chain_role(int role, IO& io) {
 }
 
 constexpr int FK_FRAMES = 32;
+#ifndef FK_BWD_OCC6
+#define FK_BWD_OCC6 3
+#endif
 template <int N>   // floats per frame, a multiple of 4; LDS rows are N + 1 apart
 __device__ __forceinline__ void fk_stream_in(const float* __restrict__ src, float* lds, int nf) {
     // every 16-byte load of the tile is issued before the first LDS write: a rolled loop keeps ONE load per thread in
@@ -797,11 +800,10 @@ struct LdsBwd1 {
 //      tensors, so thread t reads pairs t, t + 256, t + 512 straight from global memory (24 bytes of 6D, 36 of dL/dR: kept
 //      in registers, never staged), the chain leaves the induced dL/dR in the rotations' place (LdsBwd1), dL/dp is a
 //      third, small image instead of stride-288 reads inside the chain, and phase C stores its 24 bytes per pair itself.
-#ifndef FK_BWD_OCC
-#define FK_BWD_OCC 3
-#endif
-template <int RD, bool PF>
-__global__ __launch_bounds__(256, FK_BWD_OCC) void fk_bwd_aos_kernel(const float* __restrict__ rot, const float* __restrict__ offs,
+// OCC: waves per SIMD the kernel is compiled for (3: 168 registers, 16 of them spilled at RD == 6; 2: 256, none) -- both are
+// instantiated for the 6D input and picked at run time (HMVAE_FK_BWD_OCC), the matrix-input variant needs 126 either way
+template <int RD, bool PF, int OCC>
+__global__ __launch_bounds__(256, OCC) void fk_bwd_aos_kernel(const float* __restrict__ rot, const float* __restrict__ offs,
                                                          long long n, const float* __restrict__ dR_up,
                                                          const float* __restrict__ dP_up, float* __restrict__ d_rot) {
     constexpr int LR = NJ * 9 + 1, LP = NJ * 3 + 1;
@@ -1139,24 +1141,34 @@ extern "C" int hmvae_fk_bwd(const float* rot, int32_t rot_dim, const float* offs
     dim3 grid((unsigned)((n_frames + FK_FRAMES - 1) / FK_FRAMES)), block(256);
     const size_t lds = sizeof(float) * (FK_FRAMES * ((NJ * 9 + 1) + (NJ * 3 + 1)) + (pf ? FK_FRAMES * (NJ * 3 + 1) : NJ * 3 + 1) +
                                         4 * 12 * FK_FRAMES);
-#define FK_BWD_LAUNCH(RD_, PF_)                                                                                        \
+    static int occ6 = 0;
+    if (!occ6) {
+        const char* e = getenv("HMVAE_FK_BWD_OCC");
+        occ6 = (e && atoi(e) == 2) ? 2 : FK_BWD_OCC6;
+    }
+#define FK_BWD_LAUNCH(RD_, PF_, OCC_)                                                                                  \
     {                                                                                                                  \
         static bool attr = false;                                                                                      \
         if (!attr) {                                                                                                   \
-            if (hipFuncSetAttribute((const void*)fk_bwd_aos_kernel<RD_, PF_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    160 * 1024) != hipSuccess)                                                         \
+            if (hipFuncSetAttribute((const void*)fk_bwd_aos_kernel<RD_, PF_, OCC_>,                                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)             \
                 return HMVAE_ERR_LAUNCH;                                                                               \
             attr = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((fk_bwd_aos_kernel<RD_, PF_>), grid, block, lds, s, rot, offsets, (long long)n_frames, dR,  \
-                           dpos, d_rot);                                                                               \
+        hipLaunchKernelGGL((fk_bwd_aos_kernel<RD_, PF_, OCC_>), grid, block, lds, s, rot, offsets, (long long)n_frames, \
+                           dR, dpos, d_rot);                                                                           \
     }
     if (rot_dim == 6) {
-        if (pf) FK_BWD_LAUNCH(6, true)
-        else FK_BWD_LAUNCH(6, false)
+        if (occ6 == 2) {
+            if (pf) FK_BWD_LAUNCH(6, true, 2)
+            else FK_BWD_LAUNCH(6, false, 2)
+        } else {
+            if (pf) FK_BWD_LAUNCH(6, true, 3)
+            else FK_BWD_LAUNCH(6, false, 3)
+        }
     } else {
-        if (pf) FK_BWD_LAUNCH(9, true)
-        else FK_BWD_LAUNCH(9, false)
+        if (pf) FK_BWD_LAUNCH(9, true, 3)
+        else FK_BWD_LAUNCH(9, false, 3)
     }
 #undef FK_BWD_LAUNCH
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;

@@ -8,7 +8,7 @@
 TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-fk --no-kernel-timing --no-phase1"
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-fk --no-kernel-timing --no-phase1 --no-extra"
 export HMVAE_TUNE_CACHE=$R/gpurun_out/tune_${TAG}.json
 rm -f $HMVAE_TUNE_CACHE
 python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_bench.json 2> $R/gpurun_out/prof_${TAG}_bench.err &&
