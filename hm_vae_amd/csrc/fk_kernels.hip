@@ -1515,7 +1515,7 @@ constexpr int TF_FRAMES = 32;
 // TF_GROUPS: time steps (groups of 32 frames) a workgroup walks
 // C6: also write the frame-major copy of the 6D input the decode API returns (576 B/frame more to store and 18 KB more
 // LDS: two instead of four workgroups per CU); callers that only want R / positions pass c6 = NULL.
-template <bool C6, int TF_GROUPS>
+template <bool C6, int TF_GROUPS, bool ALIAS = true>
 __global__ __launch_bounds__(256) void decode_tail_fwd_kernel(const float* __restrict__ dec, const float* __restrict__ offs,
                                                               int T, int B, int bp, float* __restrict__ c6,
                                                               float* __restrict__ R, float* __restrict__ P) {
@@ -1524,8 +1524,10 @@ __global__ __launch_bounds__(256) void decode_tail_fwd_kernel(const float* __res
     // (round 3) the frame-major 6D copy is streamed out of the FRONT of sR's space before the lifted matrices are written
     // there -- two more barriers per group, but 37 instead of 56 KB of LDS: four workgroups per CU like the variant without
     // the copy (72 instead of 36 KB of loads in flight per CU; bandwidth x latency asks for ~55)
+    // (ALIAS = false: round 2's form with an image of its own for the copy, kept for the A/B: HMVAE_TF_ALIAS=0)
     __shared__ float sR[TF_FRAMES * LR];
-    float* const s6 = sR;
+    __shared__ float s6own[(C6 && !ALIAS) ? TF_FRAMES * L6 : 1];
+    float* const s6 = ALIAS ? sR : s6own;
     __shared__ float sP[TF_FRAMES * LP];
     __shared__ float sO[NJ * 3];                     // offsets: LDS broadcast reads inside the chain, no global round trips
     const size_t rs = (size_t)T * bp;
@@ -1594,9 +1596,11 @@ __global__ __launch_bounds__(256) void decode_tail_fwd_kernel(const float* __res
 #pragma unroll
                 for (int k = 0; k < 6; ++k) s6[f * L6 + j * 6 + k] = in[g][i][k];
             }
-            __syncthreads();
-            stream_out(std::integral_constant<int, NJ * 6>{}, s6, c6);
-            __syncthreads();                               // the 6D image is overwritten by the matrices
+            if constexpr (ALIAS) {
+                __syncthreads();
+                stream_out(std::integral_constant<int, NJ * 6>{}, s6, c6);
+                __syncthreads();                           // the 6D image is overwritten by the matrices
+            }
         }
         // A: lifts
 #pragma unroll
@@ -1618,6 +1622,7 @@ __global__ __launch_bounds__(256) void decode_tail_fwd_kernel(const float* __res
         }
         __syncthreads();
         // C: the matrices and the positions
+        if constexpr (C6 && !ALIAS) stream_out(std::integral_constant<int, NJ * 6>{}, s6, c6);
         stream_out(std::integral_constant<int, NJ * 9>{}, sR, R);
         stream_out(std::integral_constant<int, NJ * 3>{}, sP, P);
         __syncthreads();                                   // the image is rewritten by the next group
@@ -1712,7 +1717,15 @@ extern "C" int hmvae_decode_tail_fwd(const float* dec_out, const float* offsets,
         case 4: TF_LAUNCH(C6_, 4); break;         \
         default: TF_LAUNCH(C6_, 1); break;        \
     }
-    if (c6) {
+    static int alias = -1;
+    if (alias < 0) {
+        const char* e = getenv("HMVAE_TF_ALIAS");
+        alias = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (c6 && !alias && groups == 1) {
+        hipLaunchKernelGGL((decode_tail_fwd_kernel<true, 1, false>), dim3((B + TF_FRAMES - 1) / TF_FRAMES, T), block, 0,
+                           (hipStream_t)stream, dec_out, offsets, T, B, bp, c6, R, pos);
+    } else if (c6) {
         TF_PICK(true)
     } else {
         TF_PICK(false)

@@ -269,7 +269,10 @@ typedef struct {
     const struct hmvae_wreduce_desc_s* fused_reduce;
     /* Optional, mode 2, n_workers == 0: the tiles taken two at a time.  pair_tab[2i], pair_tab[2i+1] = a tile and the next
      * 64-column tile of the SAME row group (or -1 for a group's last, unpaired tile), n_pairs entries; a workgroup of 8
-     * waves then owns the pair and stages the gradient rows once for both.  Slab layout and reduce are unchanged. */
+     * waves then owns the pair and stages the gradient rows once for both.  Slab layout and reduce are unchanged.
+     * With pair_tab, mt may be 5..7 ("wide tiles", round 3: up to 112 rows x 128 columns per workgroup, one workgroup per CU;
+     * row groups cut evenly, dead 16-row tiles of a group cost nothing; at most four load passes over the activation
+     * windows, i.e. every 15-tap layer -- otherwise HMVAE_ERR_UNSUPPORTED); without it mt <= 4. */
     const int32_t* pair_tab;
     int32_t n_pairs;
     int32_t pad2_;
