@@ -1,3 +1,6 @@
+"""HISTORICAL (round 2): the driver that ran the graph-destroy reproducers many times to locate the fault in the bundled HIP
+7.0.2 runtime.  The cause is established (tools/repro/README.md) and the product parks graphs on that runtime; do NOT re-run this on
+the pool -- it makes a known crash happen again.  Kept as a record of how the evidence was gathered."""
 """Runs the graph-destroy abort experiments one after another on the GPU box, each as a child process under a timeout,
 logs under gpurun_out/abort/.  A child that aborts (glibc heap check) is a RESULT, the study goes on; a child that times
 out ends the study (no further GPU step after a hang).
