@@ -150,11 +150,12 @@ def instrument_gemms(engine, timer, bp):
             restore.append((side, "run", timer.wrap_op(side, "run", fam, lambda *a, _f=useful_f, _s=side, **k:
                                                        (_f * a[2], issued_per_col(_s, a[2]) * a[2]) if len(a) > 2 else (0.0, 0.0))))
         restore.append((op, "backward_weight", timer.wrap_op(op, "backward_weight",
-                                                             "wgrad (wgrad_bf3_kernel | wgrad_lds_kernel | wgrad_kernel | wreduce_kernel)",
+                                                             "wgrad (wgrad_bf3_kernel | wgrad_pq_kernel | wgrad_lds_kernel | wgrad_kernel | wreduce_kernel)",
                                                              lambda *a, _f=useful_f, **k: _f * a[3],
-                                                             pipe_fn=lambda *a, _o=op, **k: "bf16x3" if _o.wg_mode(a[3]) in (2, 3) else "fp32")))
+                                                             pipe_fn=lambda *a, _o=op, **k: "bf16x3" if (_o.wg_mode(a[3]) in (2, 3, 4) or
+                                                                                                          (k.get("src") is not None and _o.use_pq(a[3]))) else "fp32")))
     lib = _lib.load()
-    for cname in ("hmvae_gather_gemm_v2", "hmvae_gather_gemm_v3", "hmvae_gather_gemm_v4", "hmvae_wgrad_gemm", "hmvae_wgrad_reduce"):
+    for cname in ("hmvae_gather_gemm_v2", "hmvae_gather_gemm_v3", "hmvae_gather_gemm_v4", "hmvae_wgrad_gemm", "hmvae_wgrad_pq", "hmvae_wgrad_reduce"):
         restore.append((lib, cname, timer.wrap_c(lib, cname)))
     return restore
 

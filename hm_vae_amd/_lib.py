@@ -68,6 +68,15 @@ class WgradDesc(C.Structure):
                 ("fused_reduce", _ptr), ("pair_tab", _ptr), ("n_pairs", _i32), ("pad2_", _i32)]
 
 
+class WgradPqDesc(C.Structure):
+    """hmvae_wgrad_pq_desc (include/hmvae.h)."""
+    _fields_ = [("dz", _ptr), ("x", _ptr), ("dense", _ptr), ("dz_base", _ptr), ("x_base", _ptr), ("tile_r0", _ptr),
+                ("tile_c0", _ptr), ("ok", _ptr), ("child_tab", _ptr), ("child_scale", _ptr), ("m", _ptr),
+                ("n_tiles", _i32), ("n_rows", _i32), ("n_chan", _i32), ("kt", _i32), ("log_t", _i32), ("log_s", _i32),
+                ("bp", _i32), ("dz_ts", _i32), ("x_ts", _i32), ("row_stride", _i32), ("chan_stride", _i32),
+                ("child_side", _i32), ("accumulate", _i32), ("pad_", _i32)]
+
+
 class WreduceDesc(C.Structure):
     _fields_ = [("slab", _ptr), ("dense", _ptr), ("tile_g", _ptr), ("tile_col0", _ptr), ("g_ncols", _ptr),
                 ("g_choff", _ptr), ("chan_id", _ptr), ("row_id", _ptr), ("g_nc4", _ptr), ("g_okoff", _ptr), ("pair_ok", _ptr),
@@ -123,6 +132,7 @@ _SIGS = {
     "hmvae_gather_gemm_v4": ([C.POINTER(Gemm4Desc), _ptr], _i32),
     "hmvae_wgrad_gemm": ([C.POINTER(WgradDesc), _ptr], _i32),
     "hmvae_wgrad_reduce": ([C.POINTER(WreduceDesc), _ptr], _i32),
+    "hmvae_wgrad_pq": ([C.POINTER(WgradPqDesc), _ptr], _i32),
     "hmvae_pack_weights": ([_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr], _i32),
     "hmvae_wgrad_reduce_multi": ([_ptr, _ptr, _i32, _i32, _ptr], _i32),
     "hmvae_row_sums_scaled": ([_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _ptr], _i32),

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libhmvae_hip.so")
-SOURCES = ["gemm_kernels.hip", "gemm_v2.hip", "gemm_v3.hip", "gemm_v4.hip", "wgrad_lds.hip", "wgrad_bf3.hip", "elementwise_kernels.hip", "latent_bridge.hip", "fk_kernels.hip"]
+SOURCES = ["gemm_kernels.hip", "gemm_v2.hip", "gemm_v3.hip", "gemm_v4.hip", "wgrad_lds.hip", "wgrad_bf3.hip", "wgrad_pq.hip", "elementwise_kernels.hip", "latent_bridge.hip", "fk_kernels.hip"]
 
 
 def _newer(target, deps):

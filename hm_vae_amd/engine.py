@@ -36,6 +36,12 @@ FUSE_LEAKY_BWD = _os0.environ.get("HMVAE_FUSE_LEAKY_BWD", "1") != "0"
 # weight-gradient launches on wide tiles (ops wg_mode 4) are issued when their segment's data-gradient chain is through
 # (measured 1.34 -> 1.47 ms at B = 256: the chain's launches leave CUs idle that the weight gradients fill; off by default)
 DEFER_WIDE = _os0.environ.get("HMVAE_DEFER_WIDE", "0") == "1"
+# Weight gradients whose launch waits for the layer's OWN data-gradient launch (instead of running beside it): layer tags
+# "dec0,dec1,enc3".  The position-pair launch (ops.MaskedGemm.wgrad_pq) is as dense as the data-gradient gather-GEMMs, so the two
+# gain nothing from running side by side, while the launches behind the first decoder layer (latent heads, bridge: 16-48
+# workgroups) leave the chip empty.
+# Default: the operator's tuned choice (ops.MaskedGemm.wg_delay, tune file); HMVAE_WG_DELAY names the layers instead ("none": no layer).
+WG_DELAY = (set(t for t in _os0.environ["HMVAE_WG_DELAY"].split(",") if t) if "HMVAE_WG_DELAY" in _os0.environ else None)
 
 
 class VaePlan:
@@ -153,7 +159,18 @@ class _StepBase:
         self._forked.add(self._turn)
         return torch.cuda.stream(side)
 
+    def _flush_delayed(self):
+        """Queue the weight gradients that waited for the data-gradient launch just issued (WG_DELAY)."""
+        lst, self._delayed = getattr(self, "_delayed", []), []
+        self._flushing = True
+        try:
+            for args, kw in lst:
+                self._wgrad(*args, **kw)
+        finally:
+            self._flushing = False
+
     def _flush_deferred(self):
+        self._flush_delayed()
         lst, self._deferred = self._deferred, []
         self._flushing = True
         try:
@@ -171,11 +188,28 @@ class _StepBase:
                 self._stream_wait(main, self._side[i], ("join", i))
         self._forked.clear()
 
-    def _wgrad(self, op, dy, x, name, bp, w, bias=None, before=None):
+    def _wgrad(self, op, dy, x, name, bp, w, bias=None, before=None, src=None, tag=None):
         """bias: optional (src, grad_name, rows_key, base, n_out, rows_per_out, row_step) for the row-sum kernel.
-        before: launches that produce `x`, issued on the same side stream first."""
+        before: launches that produce `x`, issued on the same side stream first.
+        src: the tensor the layer's gather sides read (in front of the folded Upsample / Unpool): where the operator's tuned
+        choice is the position-pair launch (ops.MaskedGemm.use_pq) the gradient comes from it and `x` is never built."""
         if self._skip_wgrad:
             return
+        if (tag is not None and not MULTI_REDUCE and not getattr(self, "_flushing", False)
+                and ((tag in WG_DELAY) if WG_DELAY is not None else (op.wg_decided(bp) and op.wg_delay(bp)))):
+            if not hasattr(self, "_delayed"):
+                self._delayed = []
+            self._delayed.append(((op, dy, x, name, bp, w), dict(bias=bias, before=before, src=src)))
+            return
+        if src is not None and not MULTI_REDUCE:
+            if not op.wg_decided(bp):           # first eager step: time the candidates (needs x)
+                if before is not None:
+                    before()
+                op.autotune_split(dy, x, self.grad_view(name), bp, w["slabs"][id(op)], src=src)
+            if op.use_pq(bp):
+                x, before = None, None
+            else:
+                src = None
         if DEFER_WIDE and not MULTI_REDUCE and not getattr(self, "_flushing", False) and op.wg_mode(bp) == 4:
             # wide-tile launches (one 8-wave workgroup per CU holding 130 KB of LDS for the whole tile) starve the
             # data-gradient chain when they run beside it: they are queued when the segment's chain is through (_flush_deferred)
@@ -191,7 +225,7 @@ class _StepBase:
             with ctx:
                 if before is not None:
                     before()
-                op.backward_weight(dy, x, self.grad_view(name), bp, slab)
+                op.backward_weight(dy, x, self.grad_view(name), bp, slab, src=src)
                 if bias is not None:
                     src, gname, key, base, n_out, rows_per, step = bias[:7]
                     if len(bias) > 7:       # factor per output: rows averaged by a folded SkeletonPool
@@ -800,7 +834,9 @@ class VaeEngine(_StepBase):
             if conv.fused_front:
                 src = w["H0"] if i == 0 else w["D%d" % (i - 1)]
                 self._wgrad(conv, dy, w["U%d" % i], dconv[i] + ".weight", bp, w, bias,
-                            before=lambda i=i, src=src: self.dec_unpool[i].forward(src, w["U%d" % i], p.dec_ts[i], bp))
+                            before=lambda i=i, src=src: self.dec_unpool[i].forward(src, w["U%d" % i], p.dec_ts[i], bp),
+                            src=src if i < L - 1 else None,     # (the last layer reads the per-edge concat buffer)
+                            tag="dec%d" % i)
                 if i >= 1 and FUSE_LEAKY_BWD:
                     # layer i-1's LeakyReLU backward rides in this launch's epilogue (its output D[i-1] is laid out like dst;
                     # in the concat buffer only the convolution's half of every edge block went through the activation)
@@ -808,6 +844,7 @@ class VaeEngine(_StepBase):
                                                     act_base=self._concat_act_base() if i - 1 == L - 2 else None)
                 else:
                     conv.backward_data(dy, dst, bp)
+                self._flush_delayed()
             else:
                 self._wgrad(conv, dy, w["U%d" % i], dconv[i] + ".weight", bp, w, bias)
                 conv.backward_data(dy, w["dU%d" % i], bp)
@@ -937,7 +974,7 @@ class VaeEngine(_StepBase):
                     rows_p = conv.pool_dst_base[conv.pool_rmap].astype(np.int32)
                     bias_p = (w["dP%d" % i], enc_b[i], ("econvbp", i), rows_p, p.enc_cout[i], t, 1,
                               conv.pool_scale[conv.pool_rmap])
-                    self._wgrad(conv, w["dP%d" % i], x, enc_w[i], bp, w, bias_p)
+                    self._wgrad(conv, w["dP%d" % i], x, enc_w[i], bp, w, bias_p, src=x, tag="enc%d" % i)
                 else:
                     self._wgrad(conv, w["dY%d" % i], x, enc_w[i], bp, w, bias,
                                 before=lambda i=i, t=t: self.enc_pool[i].backward(w["dA%d" % i], w["A%d" % i],
@@ -946,6 +983,7 @@ class VaeEngine(_StepBase):
                     # (layer 0 in phase 2: the shallow head's gradient is added afterwards, by the launch that applies the factor)
                     self._enc_grad_into(i - 1, lambda dst, i=i, **kw: conv.backward_data(w["dP%d" % i], dst, bp, **kw), w,
                                         final=not (i - 1 == 0 and phase2))
+                self._flush_delayed()
             else:
                 self.enc_pool[i].backward(w["dA%d" % i], w["A%d" % i], w["dY%d" % i], t, bp)
                 self._wgrad(conv, w["dY%d" % i], x, enc_w[i], bp, w, bias)

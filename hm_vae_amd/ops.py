@@ -57,6 +57,11 @@ WGRAD_WIDE = _os.environ.get("HMVAE_WGRAD_WIDE", "1")
 # tile, and the data-gradient chain's gather launches cannot co-reside -- interleaved A/B of the graph step at B = 256: 1.34 ms
 # with the 48 x 64 tiles, 1.38-1.42 with wide tiles on either of the two layers, 1.47 with those launches deferred to the end
 # of their segment.  The alone-timed autotuner therefore counts the wide launch's time at WIDE_BIAS.
+# Weight gradients through the position-pair products (csrc/wgrad_pq.hip: one dense GEMM over (row, position) x (channel,
+# source position) + the contraction with the layer's position/tap relation in its epilogue): "auto" = timed against the
+# direct launch where the caller hands over the source tensor, "0" off, "1" wherever it applies ("all": also where it needs
+# more products than the direct form -- measurements only).
+WGRAD_PQ = _os.environ.get("HMVAE_WGRAD_PQ", "auto")
 WIDE_BIAS = float(_os.environ.get("HMVAE_WIDE_BIAS", "1.3"))
 _WG_FORCE = {int(t[0][1:] if t[0].startswith("t") else t[0]): (int(t[1]), int(t[2]))
              for t in (e.split(":") for e in _os.environ.get("HMVAE_WG_FORCE", "").split(",") if e)}
@@ -808,6 +813,12 @@ class MaskedGemm:
         # layers, where a block is read by 100+ output rows.  Built on demand (wide()).
         self._wide_args = (wide_src, wg_x_base, wg_dz_base) if wide_src is not None else None
         self._wide = None
+        # position-pair form (pq()): the layer's input as a linear image of the gather sides' source tensor
+        self._pq_args = dict(rows_f=rows_f, chans_f=chans_f, pairs_f=pairs_f, comp=comp, x_base=x_base, y_base=y_base,
+                             x_ts=int(x_ts), y_ts=int(y_ts))
+        self._pq = None
+        self._pq_tuned = {}
+        self._delay_tuned = {}
         self.x_ts, self.y_ts = int(x_ts), int(y_ts)
         # geometry of the position reduction for the weight gradient
         self.geom = conv_geom or dict(t_dst=len(pairs_f), t_src=len(pairs_f), stride=1, pad=0, pad_mode=_lib.PAD_REFLECT)
@@ -865,6 +876,127 @@ class MaskedGemm:
                 if self._bf3_lds(True, mt=gw.mt) is not None:
                     self._wide = self._wg_tables(gw, xb, db)
         return self._wide or None
+
+    @staticmethod
+    def pq_lds(t_dst, t_src):
+        """Mirror of pq_lds_bytes (csrc/wgrad_pq.hip): LDS bytes of the launch, or None where it does not apply."""
+        if t_dst < 1 or t_src < 1 or t_dst & (t_dst - 1) or t_src & (t_src - 1) or t_dst > 64 or t_src > 128:
+            return None
+        pq = t_dst * t_src
+        rch = (64 // t_dst) * (128 // t_src)                 # the epilogue takes the tile's rows in two halves
+        if rch < 16:
+            return None
+        gst = rch + (16 if pq * (rch + 32) * 4 <= 6 * 128 * 64 else 1)
+        lds = max((pq * gst + pq * 16) * 4, 6 * 128 * 64)
+        return lds if lds <= 160 * 1024 else None
+
+    def pq(self):
+        """Tables of the position-pair weight gradient (hmvae_wgrad_pq_desc), or None where it does not apply: position
+        counts that are not powers of two, more than 16 taps, an epilogue image beyond the LDS, or more products than the
+        direct form (t_src > taps)."""
+        if self._pq is None:
+            self._pq = False
+            a = self._pq_args
+            comp = a["comp"]
+            n_rows, n_chan, kt = self.w_shape
+            T = len(a["pairs_f"])
+            S = int(comp["n_src_pos"]) if comp is not None else int(self.geom["t_src"])
+            lds = self.pq_lds(T, S)
+            if (WGRAD_PQ != "0" and lds is not None and kt <= 16 and not self.wg_transposed
+                    and (S <= 1.1 * kt or WGRAD_PQ == "all") and T * S <= 1024):
+                from types import SimpleNamespace
+                dev = self.device
+                m = np.zeros((T * S, 16), dtype=np.float32)
+                if comp is not None:
+                    for p_, lst in enumerate(comp["pairs_eff"]):
+                        for q_, vt in lst:
+                            for k_, c_ in zip(comp["taps"][vt], comp["coefs"][vt]):
+                                if k_ >= 0:
+                                    m[p_ * S + q_, k_] += c_
+                else:
+                    for p_, lst in enumerate(a["pairs_f"]):
+                        for q_, k_ in lst:
+                            m[p_ * S + q_, k_] += 1.0
+                mask = np.zeros((n_rows, n_chan), dtype=bool)
+                for rows, chans in zip(a["rows_f"], a["chans_f"]):
+                    mask[np.ix_(np.asarray(rows, dtype=np.int64), np.asarray(chans, dtype=np.int64))] = True
+                cmap = comp.get("cmap") if comp is not None else None
+                rmap = comp.get("rmap") if (comp is not None and self.wg_pooled_dz) else None
+                child_tab = scale = None
+                side = 0
+                dz_base = np.asarray(a["y_base"], dtype=np.int64)
+                x_base = np.asarray(comp["src_base"] if comp is not None else a["x_base"], dtype=np.int64)
+                x_ts = int(comp.get("src_ts", a["x_ts"])) if comp is not None else a["x_ts"]
+                if cmap is not None:
+                    n_c = len(x_base)
+                    child_tab = -np.ones((n_c, 4), dtype=np.int32)
+                    ok = np.zeros((n_rows, n_c), dtype=np.uint8)
+                    cnt = np.zeros(n_c, dtype=np.int64)
+                    for f, cc in enumerate(np.asarray(cmap, dtype=np.int64)):
+                        i = cnt[cc]
+                        cnt[cc] += 1
+                        assert i < 4
+                        child_tab[cc, i] = f
+                        ok[:, cc] |= mask[:, f].astype(np.uint8) * np.uint8(1 << int(i))
+                elif rmap is not None:
+                    dz_base = np.asarray(comp["dst_base"], dtype=np.int64)
+                    n_r = len(dz_base)
+                    child_tab = -np.ones((n_r, 4), dtype=np.int32)
+                    ok = np.zeros((n_r, n_chan), dtype=np.uint8)
+                    cnt = np.zeros(n_r, dtype=np.int64)
+                    for r_, pr in enumerate(np.asarray(rmap, dtype=np.int64)):
+                        i = cnt[pr]
+                        cnt[pr] += 1
+                        assert i < 4
+                        child_tab[pr, i] = r_
+                        ok[pr, :] |= mask[r_, :].astype(np.uint8) * np.uint8(1 << int(i))
+                    scale = (1.0 / np.maximum(cnt, 1)).astype(np.float32)
+                    side = 1
+                else:
+                    ok = mask.astype(np.uint8)
+                R, Cn = ok.shape
+                RT, CT = 128 // T, 128 // S
+                tr, tc = [], []
+                for r0 in range(0, R, RT):
+                    for c0 in range(0, Cn, CT):
+                        if ok[r0:r0 + RT, c0:c0 + CT].any():
+                            tr.append(r0)
+                            tc.append(c0)
+                self._pq = SimpleNamespace(
+                    T=T, S=S, log_t=T.bit_length() - 1, log_s=S.bit_length() - 1, n_rows=R, n_chan=Cn, n_tiles=len(tr), lds=lds,
+                    m=torch.as_tensor(m).to(dev), ok=torch.as_tensor(np.ascontiguousarray(ok)).to(dev),
+                    dz_base=_dev(dz_base.astype(np.int32), dev), x_base=_dev(x_base.astype(np.int32), dev),
+                    tile_r0=_dev(np.asarray(tr, dtype=np.int32), dev), tile_c0=_dev(np.asarray(tc, dtype=np.int32), dev),
+                    child_tab=None if child_tab is None else _dev(child_tab.reshape(-1), dev),
+                    child_scale=None if scale is None else torch.as_tensor(scale).to(dev), child_side=side,
+                    dz_ts=a["y_ts"], x_ts=x_ts, m_host=m, ok_host=ok, macs_per_col=len(tr) * 128 * 128)
+        return self._pq or None
+
+    def use_pq(self, bp):
+        """The tuned (or forced) choice for this batch size: position-pair launch instead of the direct one."""
+        if WGRAD_PQ == "0" or self.pq() is None:
+            return False
+        if WGRAD_PQ in ("1", "all"):
+            only = _os.environ.get("HMVAE_WGRAD_PQ_ONLY")         # measurements: "8x4,16x8" = t_dst x t_src of the layers forced
+            return only is None or ("%dx%d" % (self._pq.T, self._pq.S)) in only.split(",")
+        return bool(self._pq_tuned.get(bp, False))
+
+    def wg_delay(self, bp):
+        """The tuned placement of this layer's weight gradient in the step: True = queued when the layer's own data-gradient
+        launch has been issued (engine._wgrad), False = beside it."""
+        return bool(self._delay_tuned.get(bp, False))
+
+    def wgrad_pq(self, dy, src, dw, bp, accumulate=False):
+        """dW (+)= the weight gradient from the gradient rows `dy` and the gather sides' SOURCE tensor `src` (one launch)."""
+        t = self.pq()
+        n_rows, n_chan, kt = self.w_shape
+        d = _lib.WgradPqDesc(_lib.ptr(dy), _lib.ptr(src), _lib.ptr(dw), _lib.ptr(t.dz_base), _lib.ptr(t.x_base),
+                             _lib.ptr(t.tile_r0), _lib.ptr(t.tile_c0), _lib.ptr(t.ok),
+                             None if t.child_tab is None else _lib.ptr(t.child_tab),
+                             None if t.child_scale is None else _lib.ptr(t.child_scale), _lib.ptr(t.m),
+                             t.n_tiles, t.n_rows, t.n_chan, kt, t.log_t, t.log_s, int(bp), t.dz_ts, t.x_ts,
+                             n_chan * kt, kt, t.child_side, 1 if accumulate else 0, 0)
+        _lib.check(_lib.load().hmvae_wgrad_pq(C.byref(d), _lib.stream()), "wgrad_pq")
 
     def _tabs(self, bp):
         """The tiling this batch size's weight-gradient launch runs on."""
@@ -1071,8 +1203,13 @@ class MaskedGemm:
                                                      self._k_chunks(bp), int(self.wg_transposed),
                                                      0 if w is None else w.n_tiles * 8 + w.g.mt, bp)
 
-    def autotune_split(self, dy, x, dw, bp, slab):
-        if bp in self._split_tuned or not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+    def wg_decided(self, bp):
+        """The launch shape for this batch size is settled (tuned, read from the tune file, or tuning is off)."""
+        return bp in self._split_tuned or not AUTOTUNE or torch.cuda.is_current_stream_capturing()
+
+    def autotune_split(self, dy, x, dw, bp, slab, src=None):
+        """src: the gather sides' source tensor -- with it the position-pair launch (pq()) is a candidate."""
+        if self.wg_decided(bp):
             return
         ck = self.wg_tune_key(bp)
         hit = _tune_cache_get(ck)
@@ -1087,6 +1224,8 @@ class MaskedGemm:
             self._split_tuned[bp] = "p" if hit[0] == "p" else int(hit[0])
             self._bf_tuned[bp] = bool(hit[1]) if len(hit) > 1 else False
             self._mode_tuned[bp] = int(hit[2]) if len(hit) > 2 else 0
+            self._pq_tuned[bp] = bool(hit[3]) if len(hit) > 3 else False
+            self._delay_tuned[bp] = bool(hit[4]) if len(hit) > 4 else False
             return
         scratch = torch.empty_like(dw)
         best = None
@@ -1124,10 +1263,27 @@ class MaskedGemm:
         self._split_tuned[bp] = best[1]
         self._bf_tuned[bp] = best[2]
         self._mode_tuned[bp] = best[3]
-        _tune_cache_put(ck, (best[1], int(best[2]), int(best[3])))
+        use_pq = False
+        if src is not None and WGRAD_PQ == "auto" and self.pq() is not None:
+            t_pq = self.fwd._time(lambda: self.wgrad_pq(dy, src, scratch, bp))
+            use_pq = t_pq < best[0]
+        self._pq_tuned[bp] = use_pq
+        # alone-timed tuning cannot see the step: a position-pair launch is queued behind the layer's data-gradient launch
+        # (wg_delay) -- what the in-step measurements found for every layer where it is kept
+        self._delay_tuned[bp] = use_pq
+        _tune_cache_put(ck, (best[1], int(best[2]), int(best[3]), int(use_pq), int(use_pq)))
 
-    def backward_weight(self, dy, x, dw, bp, slab, accumulate=False):
-        self.autotune_split(dy, x, dw, bp, slab)
+    def backward_weight(self, dy, x, dw, bp, slab, accumulate=False, src=None):
+        """src: optionally the gather sides' source tensor (the coarse tensor in front of Upsample + Unpool for a decoder
+        convolution, else the layer's own input); where use_pq(bp) says so the gradient then comes from it in one launch and
+        `x` is not read (it may be None once wg_decided(bp))."""
+        if x is not None:
+            self.autotune_split(dy, x, dw, bp, slab, src=src)
+        if src is not None and self.use_pq(bp):
+            self.wgrad_pq(dy, src, dw, bp, accumulate)
+            return
+        if x is None:
+            raise _lib.HmvaeError("backward_weight: no input tensor and the position-pair launch is not this layer's choice")
         if self.wgrad_gemm(dy, x, bp, slab, dw=dw, accumulate=accumulate):
             return                                   # the GEMM's epilogue wrote the dense gradient itself
         r = self.reduce_desc(slab, dw, bp, accumulate)

@@ -280,6 +280,44 @@ typedef struct {
 
 int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Weight gradient of a convolution over few positions through the position-pair products (round 3).
+ * The layer's input is a LINEAR image of a source tensor a (reflection padding; in the Decoder also nn.Upsample(x2, linear)
+ * and SkeletonUnpool, seq_two_hier_sa_vae.py:233-242):  xin[c, pos(p, k)] = sum_q M[p, q, k] a[c, q], hence
+ *     dW[row, chan, k] = sum_{p, q} M[p, q, k] * G[row, p, chan, q],   G = sum_b dz[row, p, b] * a[chan, q, b]
+ * (backward of skeleton.py:95-105).  G is one dense GEMM over the batch -- t_dst * t_src products per weight instead of
+ * t_dst * kt -- and the contraction with M runs in the same launch, which writes the dense gradient (mask, children of a
+ * packed channel / row as in hmvae_wreduce_desc).  fp32-grade: three exact bf16 planes per operand, six cross terms, fp32
+ * accumulation (as hmvae_wgrad_desc.mode 2); the contraction in fp32.
+ *   dz row of (row r, position p) = dz_base[r] + p * dz_ts;  a row of (channel c, position q) = x_base[c] + q * x_ts; bp floats
+ *   each.  t_dst = 1 << log_t (<= 64), t_src = 1 << log_s (<= 128), powers of two.  A tile = (128 >> log_t) rows x (128 >> log_s)
+ *   channels starting at (tile_r0, tile_c0); tiles whose mask bytes are all zero need not be listed.
+ *   ok[r * n_chan + c]: bit i = child i of the packed id on the child side takes the value (bit 0 alone without child_tab).
+ *   m[(p * t_src + q) * 16 + k] = M[p, q, k], zero for k >= kt.
+ * HMVAE_ERR_UNSUPPORTED when the epilogue's image (t_dst * t_src * (8192 / (t_dst * t_src) + 17) floats) exceeds the LDS.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* dz;
+    const float* x;
+    float* dense;
+    const int32_t* dz_base;    /* [n_rows] */
+    const int32_t* x_base;     /* [n_chan] */
+    const int32_t* tile_r0;    /* [n_tiles] */
+    const int32_t* tile_c0;    /* [n_tiles] */
+    const uint8_t* ok;         /* [n_rows][n_chan] */
+    const int32_t* child_tab;  /* [n][4] dense ids of the children (-1 unused) or NULL */
+    const float* child_scale;  /* NULL, or a factor per packed id on the child side */
+    const float* m;            /* [t_dst * t_src][16] */
+    int32_t n_tiles, n_rows, n_chan, kt;
+    int32_t log_t, log_s, bp, dz_ts, x_ts;
+    int32_t row_stride, chan_stride;   /* of the dense tensor, in floats (tap stride 1) */
+    int32_t child_side;        /* 0: children are channels, 1: rows */
+    int32_t accumulate;
+    int32_t pad_;
+} hmvae_wgrad_pq_desc;
+
+int hmvae_wgrad_pq(const hmvae_wgrad_pq_desc* desc, hmvae_stream_t stream);
+
 /* x[i] -> planes[p * plane_stride + i], p = 0..2: the exact three-way bf16 split of an fp32 tensor (each plane is the
  * round-to-nearest bf16 of the running remainder: x = p0 + p1 + p2 exactly), n a multiple of 8.  Elements n .. plane_stride
  * of a plane are not touched: hmvae_wgrad_desc.mode 2 reads the last 32 of them as its zero row (plane_stride >= n + 32,

@@ -135,6 +135,52 @@ def emu_wgrad(op, dy, x, dw):
     return dw
 
 
+def emu_wgrad_pq(op, dy, src, dw, accumulate=False):
+    """The position-pair weight gradient (csrc/wgrad_pq.hip) walked over the device tables of ops.MaskedGemm.pq(): per tile
+    G = dy rows x source rows over the batch, contraction with m[pq][k], masked scatter to the children.  dy, src: numpy
+    [rows, bp]; dw dense (n_rows, n_chan, kt)."""
+    t = op.pq()
+    assert t is not None
+    T, S = t.T, t.S
+    RT, CT = 128 // T, 128 // S
+    m = t.m_host.reshape(T, S, 16).astype(np.float64)
+    ok = t.ok_host
+    dzb, xb = _np(t.dz_base), _np(t.x_base)
+    ctab = None if t.child_tab is None else _np(t.child_tab).reshape(-1, 4)
+    scale = None if t.child_scale is None else _np(t.child_scale)
+    n_rows, n_chan, kt = op.w_shape
+    dwf = dw.reshape(n_rows, n_chan, kt)
+    seen = set()
+    for r0, c0 in zip(_np(t.tile_r0), _np(t.tile_c0)):
+        assert r0 % RT == 0 and c0 % CT == 0 and (r0, c0) not in seen
+        seen.add((r0, c0))
+        rows = list(range(r0, min(r0 + RT, t.n_rows)))
+        chans = list(range(c0, min(c0 + CT, t.n_chan)))
+        A = np.stack([dy[dzb[r] + p * t.dz_ts] for r in rows for p in range(T)]).astype(np.float64)
+        Bm = np.stack([src[xb[c] + q * t.x_ts] for c in chans for q in range(S)]).astype(np.float64)
+        G = (A @ Bm.T).reshape(len(rows), T, len(chans), S)
+        Sk = np.einsum("rpcq,pqk->rck", G, m)
+        for ri, r in enumerate(rows):
+            for ci, c in enumerate(chans):
+                bits = int(ok[r, c])
+                if not bits:
+                    continue
+                v = Sk[ri, ci, :kt]
+                if ctab is None:
+                    dwf[r, c, :] = (dwf[r, c, :] if accumulate else 0) + v
+                    continue
+                v = v * (float(scale[r if t.child_side else c]) if scale is not None else 1.0)
+                for k in range(4):
+                    if (bits >> k) & 1:
+                        dr, dc = (ctab[r, k], c) if t.child_side else (r, ctab[c, k])
+                        dwf[dr, dc, :] = (dwf[dr, dc, :] if accumulate else 0) + v
+    # tiles that are not listed hold no live pair
+    for r0 in range(0, t.n_rows, RT):
+        for c0 in range(0, t.n_chan, CT):
+            assert (r0, c0) in seen or not ok[r0:r0 + RT, c0:c0 + CT].any()
+    return dw
+
+
 # ---- fourth-generation gather-GEMM (csrc/gemm_v4.hip): bf16 planes in A-operand order, K steps of 32 channels ----
 def bf16_split3(x):
     """x (float32 array) -> three uint16 arrays of bf16 bit patterns with x == p0 + p1 + p2 exactly (round to nearest

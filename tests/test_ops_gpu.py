@@ -807,6 +807,101 @@ def test_wgrad_lds_staged_kernel_matches_direct(dev, monkeypatch, cfg):
     assert max(worst[m] for m in modes if m in ("2", "3")) <= 1.5 * worst["0"] + 1e-7, worst
 
 
+@pytest.mark.parametrize("case", [
+    dict(kind="dec", level=3, ch=96, co=48, Tc=4, B=70),        # first decoder layer: 8 x 4 position pairs, dense mask
+    dict(kind="dec", level=2, ch=48, co=24, Tc=8, B=33),        # second: 16 x 8, unpooled edges (children), masked tiles
+    dict(kind="dec", level=1, ch=5, co=3, Tc=4, B=256),         # ragged tiles: rows / channels not multiples of the tile
+    dict(kind="enc", level=2, ci=24, co=48, T=16, B=70),        # stride 2 + folded SkeletonPool: children are rows (x 1/2)
+    dict(kind="plain", T=16, B=5),                              # no composite at all: reflection only, 16 x 16 pairs
+])
+def test_wgrad_position_pairs_match_float64(dev, monkeypatch, case):
+    """hmvae_wgrad_pq (csrc/wgrad_pq.hip): the weight gradient as ONE dense GEMM over (row, position) x (channel, source
+    position) pairs on the bf16 pipe (three planes, six cross terms) + the contraction with the layer's position / tap
+    relation in the epilogue, read from the tensor IN FRONT of Upsample / Unpool (decoder) or the layer's own input --
+    against a float64 evaluation of the reference's arithmetic (skeleton.py:95-105 behind seq_two_hier_sa_vae.py:233-242),
+    masked entries untouched, accumulate."""
+    from hm_vae_amd import ops, topology
+    torch.manual_seed(5)
+    monkeypatch.setattr(ops, "WGRAD_PQ", "1")
+    K, pad, B = 15, 7, case["B"]
+    if case["kind"] == "plain":
+        neigh = [[0, 1], [0, 1, 2], [1, 2]]
+        cin, cout, T = 3 * 7, 3 * 9, case["T"]
+        op = ops.conv_gemm(dev, neigh, cin, cout, K, 1, pad, "reflect", T, need_dx=True)
+        mask = O.conv_mask(neigh, cin, cout, K).double()
+        xs_b = torch.randn(B, cin, T, dtype=torch.float64)
+        wt = torch.zeros(cout, cin, K, dtype=torch.float64, requires_grad=True)
+        y = O.skel_conv(xs_b, wt, mask, None, 1, pad, "reflect")
+        src_b, n_src, t_src, t_out = xs_b, cin, T, T
+    else:
+        edges = topology.edges_from_parents(topology.SMPL24_PARENTS)
+        for _ in range(case["level"]):
+            edges = topology.derive_pooling(edges)[2]
+        pooling = topology.derive_pooling(edges)[1] if case["level"] < 3 or case["kind"] == "enc" else [[i] for i in range(len(edges))]
+        neigh = topology.find_neighbor(edges, 2)
+        n_f, n_c = len(neigh), len(pooling)
+        if case["kind"] == "dec":
+            usrc = np.zeros(n_f, dtype=np.int64)
+            for i, grp in enumerate(pooling):
+                for j in grp:
+                    usrc[j] = i
+            ch, Tc = case["ch"], case["Tc"]
+            cin, cout, T = n_f * ch, n_f * case["co"], 2 * Tc
+            op = ops.conv_gemm(dev, neigh, cin, cout, K, 1, pad, "reflect", T, need_dx=True, upsample=True, unpool_src=usrc)
+            mask = O.conv_mask(neigh, cin, cout, K).double()
+            src_b = torch.randn(B, n_c * ch, Tc, dtype=torch.float64)
+            idx = torch.as_tensor((usrc[:, None] * ch + np.arange(ch)[None, :]).reshape(-1))
+            U = F.interpolate(src_b[:, idx, :], scale_factor=2, mode="linear", align_corners=False)
+            wt = torch.zeros(cout, cin, K, dtype=torch.float64, requires_grad=True)
+            y = O.skel_conv(U, wt, mask, None, 1, pad, "reflect")
+            n_src, t_src, t_out = n_c * ch, Tc, T
+        else:
+            ci, co, T = case["ci"], case["co"], case["T"]
+            cin, cout = n_f * ci, n_f * co
+            op = ops.conv_gemm(dev, neigh, cin, cout, K, 2, pad, "reflect", T, need_dx=True, pool_groups=pooling)
+            mask = O.conv_mask(neigh, cin, cout, K).double()
+            src_b = torch.randn(B, cin, T, dtype=torch.float64)
+            wt = torch.zeros(cout, cin, K, dtype=torch.float64, requires_grad=True)
+            yc = O.skel_conv(src_b, wt, mask, None, 2, pad, "reflect")
+            Pm = torch.zeros(n_c * co, cout, dtype=torch.float64)
+            for i, grp in enumerate(pooling):
+                for j in grp:
+                    for c in range(co):
+                        Pm[i * co + c, j * co + c] = 1.0 / len(grp)
+            y = torch.einsum("pr,brt->bpt", Pm, yc)              # the pooled pre-activation: what the launch is handed
+            n_src, t_src, t_out = cin, T, yc.shape[2]
+    t = op.pq()
+    assert t is not None and (t.T, t.S) == (t_out, t_src)
+    gy = torch.randn_like(y)
+    (y * gy).sum().backward()
+    exact = wt.grad.numpy()
+    bp = ops.pad_batch(B)
+    dys = torch.zeros(y.shape[1] * t_out, bp, device=dev)
+    dys[:, :B] = gy.permute(1, 2, 0).reshape(-1, B).float().to(dev)
+    srcs = torch.zeros(n_src * t_src, bp, device=dev)
+    srcs[:, :B] = src_b.permute(1, 2, 0).reshape(-1, B).float().to(dev)
+    if case["kind"] == "dec" and case["level"] == 2:
+        assert t.n_tiles < -(-t.n_rows // (128 // t.T)) * -(-t.n_chan // (128 // t.S))      # fully masked tiles are not launched
+    mk = torch.from_numpy(mask.numpy()).float().to(dev)
+    dw = torch.full((cout, cin, K), 7.0, device=dev) * mk
+    assert op.use_pq(bp)
+    op.backward_weight(dys, None, dw, bp, None, src=srcs)
+    got = dw.cpu().numpy()
+    assert float(np.abs(exact).max()) > 0
+    assert rel_err(got, exact) < 2e-6
+    assert float(np.abs(got * (1 - mask.numpy())).max()) == 0.0
+    op.backward_weight(dys, None, dw, bp, None, accumulate=True, src=srcs)
+    assert rel_err(dw.cpu().numpy(), 2.0 * exact) < 2e-6
+    # the direct launch on the layer's own input agrees
+    if case["kind"] == "dec":
+        monkeypatch.setattr(ops, "WGRAD_PQ", "0")
+        us = torch.zeros(cin * T, bp, device=dev)
+        us[:, :B] = U.permute(1, 2, 0).reshape(-1, B).float().to(dev)
+        dw2 = torch.zeros(cout, cin, K, device=dev)
+        op.backward_weight(dys, us, dw2, bp, torch.empty(op.slab_floats(bp), device=dev), src=srcs)
+        assert rel_err(dw2.cpu().numpy(), got) < 4e-6
+
+
 @pytest.mark.parametrize("cfg", [
     dict(rows=28, ch=12, neigh=[[0, 1, 2, 3]] * 4, kt=15, stride=1, pad=7, mode="reflect", t_in=8, B=70),      # 112 rows: mt 7
     dict(rows=24, ch=12, neigh=[[0, 1, 2, 3]] * 4, kt=15, stride=2, pad=7, mode="reflect", t_in=16, B=64),     # 96 rows: mt 6

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 from oracle import hmvae_oracle as O
 from hm_vae_amd import ops, planner, topology
 from hm_vae_amd import planner as P
-from emu import emu_pack, emu_gather, emu_wgrad, emu_pack4, emu_gather4
+from emu import emu_pack, emu_gather, emu_wgrad, emu_wgrad_pq, emu_pack4, emu_gather4
 from helpers import rel_err
 
 
@@ -171,6 +171,15 @@ def test_conv_behind_upsample_unpool_reproduces_oracle(case):
     dw = np.zeros((cout, cin, K), dtype=np.float32)
     emu_wgrad(op, to_soa(gy), to_soa(U.detach()), dw)              # the weight gradient keeps the conv's own input
     assert rel_err(dw, (w.grad * mask).numpy()) < 1e-5
+    # ... or comes from the COARSE tensor through the position-pair products (csrc/wgrad_pq.hip; powers of two, few positions)
+    assert (op.pq() is not None) == (case["Tc"] in (4, 8))
+    if op.pq() is not None:
+        dw2 = np.full((cout, cin, K), 5.0, dtype=np.float32) * mask.numpy()
+        emu_wgrad_pq(op, to_soa(gy), to_soa(xc.detach()), dw2)
+        assert rel_err(dw2, (w.grad * mask).numpy()) < 1e-5
+        assert float(np.abs(dw2 * (1 - mask.numpy())).max()) == 0.0
+        emu_wgrad_pq(op, to_soa(gy), to_soa(xc.detach()), dw2, accumulate=True)
+        assert rel_err(dw2, 2.0 * (w.grad * mask).numpy()) < 1e-5
 
 
 @pytest.mark.parametrize("case", [
@@ -225,6 +234,11 @@ def test_conv_followed_by_pool_reproduces_oracle(case):
     emu_wgrad(op, to_soa(pre.grad if op.wg_pooled_dz else y.grad), to_soa(x.detach()), dw)
     assert op.wg_pooled_dz
     assert rel_err(dw, (w.grad * mask).numpy()) < 1e-5
+    if op.pq() is not None:          # pooled rows: one product, every child row written with the mean's factor
+        dw2 = np.zeros((cout, cin, K), dtype=np.float32)
+        emu_wgrad_pq(op, to_soa(pre.grad), to_soa(x.detach()), dw2)
+        assert rel_err(dw2, (w.grad * mask).numpy()) < 1e-5
+    assert (op.pq() is not None) == (case["T"] in (8, 16) and K == 15), (case, op.pq() is not None)
 
 
 def test_linear_tables_reproduce_oracle():

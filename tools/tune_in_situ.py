@@ -173,6 +173,7 @@ def main():
                 label = obj.tune_key(bp)
             else:
                 cur = (obj._split_tuned[bp], obj._mode_tuned.get(bp, 0))
+                place0 = (bool(obj._pq_tuned.get(bp, False)), bool(obj._delay_tuned.get(bp, False)))
                 modes = [0] + ([1] if obj.lds_eligible() else []) + ([2] if (ops.WGRAD_BF3 and obj.bf3_eligible()) else []) + \
                     ([3] if (ops.WGRAD_BF3 and obj.lds_eligible() and obj.pair_eligible()) else [])
                 splits = [c for c in obj.split_candidates(bp) if not a.fast or c in (1, 2, 3, 4, 6, 8)]
@@ -188,6 +189,20 @@ def main():
                     if t < best_t - noise:
                         best_c, best_t = (c, m), t
                 obj._split_tuned[bp], obj._mode_tuned[bp] = best_c
+                # the position-pair launch and the launch's place in the step (beside / behind the layer's data gradient)
+                best_p = place0
+                for pl in ((False, False), (False, True), (True, False), (True, True)):
+                    if pl == place0 or (pl[0] and obj.pq() is None):
+                        continue
+                    obj._pq_tuned[bp], obj._delay_tuned[bp] = pl
+                    t = measure()
+                    if VERBOSE:
+                        print("    try", obj.wg_tune_key(bp), "pq/delay", pl, "%.4f" % t, flush=True)
+                    if t < best_t - noise:
+                        best_p, best_t = pl, t
+                obj._pq_tuned[bp], obj._delay_tuned[bp] = best_p
+                if best_p != place0:
+                    best_c = tuple(best_c) + ("pq%d delay%d" % best_p,)
                 label = obj.wg_tune_key(bp)
             if best_t < base - noise:
                 print("  %-58s %s -> %s   %.4f -> %.4f ms" % (label, cur, best_c, base, best_t), flush=True)
@@ -210,7 +225,8 @@ def main():
             c = obj._tuned_v4.get(bp)
             out[obj.tune_key(bp) + "_v4"] = list(c) if c else [0]
         else:
-            out[obj.wg_tune_key(bp)] = [obj._split_tuned[bp], 0, int(obj._mode_tuned.get(bp, 0))]
+            out[obj.wg_tune_key(bp)] = [obj._split_tuned[bp], 0, int(obj._mode_tuned.get(bp, 0)),
+                                        int(bool(obj._pq_tuned.get(bp, False))), int(bool(obj._delay_tuned.get(bp, False)))]
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=0, sort_keys=True)
     print("wrote %d entries to %s" % (len(out), a.out), flush=True)
