@@ -41,7 +41,9 @@ DEFER_WIDE = _os0.environ.get("HMVAE_DEFER_WIDE", "0") == "1"
 # gain nothing from running side by side, while the launches behind the first decoder layer (latent heads, bridge: 16-48
 # workgroups) leave the chip empty.
 # Default: the operator's tuned choice (ops.MaskedGemm.wg_delay, tune file); HMVAE_WG_DELAY names the layers instead ("none": no layer).
-WG_DELAY = (set(t for t in _os0.environ["HMVAE_WG_DELAY"].split(",") if t) if "HMVAE_WG_DELAY" in _os0.environ else None)
+# ("dec1:2": behind the NEXT layer's data-gradient launch.)
+WG_DELAY = ({t.split(":")[0]: int(t.split(":")[1]) if ":" in t else 1 for t in _os0.environ["HMVAE_WG_DELAY"].split(",") if t}
+            if "HMVAE_WG_DELAY" in _os0.environ else None)
 
 
 class VaePlan:
@@ -159,18 +161,21 @@ class _StepBase:
         self._forked.add(self._turn)
         return torch.cuda.stream(side)
 
-    def _flush_delayed(self):
+    def _flush_delayed(self, force=False):
         """Queue the weight gradients that waited for the data-gradient launch just issued (WG_DELAY)."""
         lst, self._delayed = getattr(self, "_delayed", []), []
         self._flushing = True
         try:
-            for args, kw in lst:
-                self._wgrad(*args, **kw)
+            for args, kw, n in lst:
+                if n > 1 and not force:
+                    self._delayed.append((args, kw, n - 1))
+                else:
+                    self._wgrad(*args, **kw)
         finally:
             self._flushing = False
 
     def _flush_deferred(self):
-        self._flush_delayed()
+        self._flush_delayed(force=True)
         lst, self._deferred = self._deferred, []
         self._flushing = True
         try:
@@ -196,10 +201,11 @@ class _StepBase:
         if self._skip_wgrad:
             return
         if (tag is not None and not MULTI_REDUCE and not getattr(self, "_flushing", False)
-                and ((tag in WG_DELAY) if WG_DELAY is not None else (op.wg_decided(bp) and op.wg_delay(bp)))):
+                and ((tag in WG_DELAY) if WG_DELAY is not None else (op.wg_decided(bp) and op.wg_delay(bp) > 0))):
             if not hasattr(self, "_delayed"):
                 self._delayed = []
-            self._delayed.append(((op, dy, x, name, bp, w), dict(bias=bias, before=before, src=src)))
+            self._delayed.append(((op, dy, x, name, bp, w), dict(bias=bias, before=before, src=src),
+                                  WG_DELAY.get(tag, 1) if WG_DELAY is not None else op.wg_delay(bp)))
             return
         if src is not None and not MULTI_REDUCE:
             if not op.wg_decided(bp):           # first eager step: time the candidates (needs x)

@@ -671,7 +671,7 @@ class MaskedGemm:
     """
 
     def __init__(self, device, w_shape, rows_f, chans_f, rows_b, chans_b, pairs_f, pairs_b, x_base, y_base, x_ts, y_ts,
-                 conv_geom=None, bias_rows=None, composite=None, v4=False):
+                 conv_geom=None, bias_rows=None, composite=None, v4=False, wg_lists=None):
         n_rows, n_chan, kt = w_shape
         self.w_shape = tuple(int(v) for v in w_shape)
         self.kt = int(kt)
@@ -770,6 +770,10 @@ class MaskedGemm:
         gw = gf
         self.wg_child = None                 # (child_tab, child_side, child_scale) of a deduplicated weight gradient
         wg_x_base, wg_dz_base = x_base, y_base
+        # the transposed relation, for the TILING of the weight gradient alone, where no data gradient is wanted (wg_lists:
+        # the first encoder layer -- it is the last launch chain of the backward pass, nothing runs beside it)
+        if rows_b is None and wg_lists is not None and _os.environ.get("HMVAE_WGRAD_LISTS", "1") != "0":
+            rows_b, chans_b = wg_lists
         dedupe = (comp is not None and rows_b is not None and (comp.get("cmap") is not None or comp.get("rmap") is not None)
                   and _os.environ.get("HMVAE_WGRAD_DEDUPE", "1") != "0")
         wide_src = None                      # (rows_b, chans_b, pair_bits) of the weight-gradient grouping, for wide()
@@ -982,9 +986,9 @@ class MaskedGemm:
         return bool(self._pq_tuned.get(bp, False))
 
     def wg_delay(self, bp):
-        """The tuned placement of this layer's weight gradient in the step: True = queued when the layer's own data-gradient
-        launch has been issued (engine._wgrad), False = beside it."""
-        return bool(self._delay_tuned.get(bp, False))
+        """The tuned placement of this layer's weight gradient in the step: 0 = beside the layer's own data-gradient launch,
+        n = queued when the n-th data-gradient launch from there on has been issued (engine._wgrad)."""
+        return int(self._delay_tuned.get(bp, 0))
 
     def wgrad_pq(self, dy, src, dw, bp, accumulate=False):
         """dW (+)= the weight gradient from the gradient rows `dy` and the gather sides' SOURCE tensor `src` (one launch)."""
@@ -1225,7 +1229,7 @@ class MaskedGemm:
             self._bf_tuned[bp] = bool(hit[1]) if len(hit) > 1 else False
             self._mode_tuned[bp] = int(hit[2]) if len(hit) > 2 else 0
             self._pq_tuned[bp] = bool(hit[3]) if len(hit) > 3 else False
-            self._delay_tuned[bp] = bool(hit[4]) if len(hit) > 4 else False
+            self._delay_tuned[bp] = int(hit[4]) if len(hit) > 4 else 0
             return
         scratch = torch.empty_like(dw)
         best = None
@@ -1270,7 +1274,7 @@ class MaskedGemm:
         self._pq_tuned[bp] = use_pq
         # alone-timed tuning cannot see the step: a position-pair launch is queued behind the layer's data-gradient launch
         # (wg_delay) -- what the in-step measurements found for every layer where it is kept
-        self._delay_tuned[bp] = use_pq
+        self._delay_tuned[bp] = int(use_pq)
         _tune_cache_put(ck, (best[1], int(best[2]), int(best[3]), int(use_pq), int(use_pq)))
 
     def backward_weight(self, dy, x, dw, bp, slab, accumulate=False, src=None):
@@ -1476,7 +1480,8 @@ def conv_gemm(device, neigh, cin, cout, kt, stride, pad, pad_mode, t_in, need_dx
     if composite is None and (upsample or unpool_src is not None or pool_groups is not None):
         raise _lib.HmvaeError("the layers around this convolution cannot be folded into it (HMVAE_FOLD=0 or limits)")
     op = MaskedGemm(device, (cout, cin, kt), rows_f, chans_f, rows_b, chans_b, pairs_f, pairs_b, x_base, y_base, 1, 1,
-                    conv_geom=geom, composite=composite, v4=True)
+                    conv_geom=geom, composite=composite, v4=True,
+                    wg_lists=None if need_dx else P.conv_joint_lists_transposed(neigh, cin, cout))
     op.t_in, op.t_out = t_in, t_out
     op.fused_front = bool(upsample or unpool_src is not None)
     op.fused_pool = pool_groups is not None

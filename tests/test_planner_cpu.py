@@ -234,6 +234,12 @@ def test_conv_followed_by_pool_reproduces_oracle(case):
     emu_wgrad(op, to_soa(pre.grad if op.wg_pooled_dz else y.grad), to_soa(x.detach()), dw)
     assert op.wg_pooled_dz
     assert rel_err(dw, (w.grad * mask).numpy()) < 1e-5
+    # the first encoder layer wants no data gradient: its weight gradient is still tiled by input block over the pooled rows
+    op0 = ops.conv_gemm("cpu", neigh, cin, cout, K, st, pad, "reflect", T, need_dx=False, pool_groups=pooling)
+    assert op0.bwd is None and op0.wg_pooled_dz
+    dw0 = np.zeros((cout, cin, K), dtype=np.float32)
+    emu_wgrad(op0, to_soa(pre.grad), to_soa(x.detach()), dw0)
+    assert rel_err(dw0, (w.grad * mask).numpy()) < 1e-5
     if op.pq() is not None:          # pooled rows: one product, every child row written with the mean's factor
         dw2 = np.zeros((cout, cin, K), dtype=np.float32)
         emu_wgrad_pq(op, to_soa(pre.grad), to_soa(x.detach()), dw2)

@@ -173,7 +173,7 @@ def main():
                 label = obj.tune_key(bp)
             else:
                 cur = (obj._split_tuned[bp], obj._mode_tuned.get(bp, 0))
-                place0 = (bool(obj._pq_tuned.get(bp, False)), bool(obj._delay_tuned.get(bp, False)))
+                place0 = (bool(obj._pq_tuned.get(bp, False)), int(obj._delay_tuned.get(bp, 0)))
                 modes = [0] + ([1] if obj.lds_eligible() else []) + ([2] if (ops.WGRAD_BF3 and obj.bf3_eligible()) else []) + \
                     ([3] if (ops.WGRAD_BF3 and obj.lds_eligible() and obj.pair_eligible()) else [])
                 splits = [c for c in obj.split_candidates(bp) if not a.fast or c in (1, 2, 3, 4, 6, 8)]
@@ -191,7 +191,7 @@ def main():
                 obj._split_tuned[bp], obj._mode_tuned[bp] = best_c
                 # the position-pair launch and the launch's place in the step (beside / behind the layer's data gradient)
                 best_p = place0
-                for pl in ((False, False), (False, True), (True, False), (True, True)):
+                for pl in ((False, 0), (False, 1), (True, 0), (True, 1), (True, 2)):
                     if pl == place0 or (pl[0] and obj.pq() is None):
                         continue
                     obj._pq_tuned[bp], obj._delay_tuned[bp] = pl
@@ -226,7 +226,7 @@ def main():
             out[obj.tune_key(bp) + "_v4"] = list(c) if c else [0]
         else:
             out[obj.wg_tune_key(bp)] = [obj._split_tuned[bp], 0, int(obj._mode_tuned.get(bp, 0)),
-                                        int(bool(obj._pq_tuned.get(bp, False))), int(bool(obj._delay_tuned.get(bp, False)))]
+                                        int(bool(obj._pq_tuned.get(bp, False))), int(obj._delay_tuned.get(bp, 0))]
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=0, sort_keys=True)
     print("wrote %d entries to %s" % (len(out), a.out), flush=True)
