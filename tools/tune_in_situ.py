@@ -37,7 +37,8 @@ def main():
     ap.add_argument("--seq-len", type=int, default=0, help="override train_seq_len (trajectory model: config 5 quotes 64)")
     ap.add_argument("--fast", action="store_true", help="weight-gradient splits 1, 2, 3, 4, 6, 8 only")
     ap.add_argument("--no-v4", action="store_true", help="leave the v4 (bf16-plane) gather choices as the autotuner made them")
-    ap.add_argument("--only", default="", help="comma list of knob kinds to walk: g, g4, w (default: all)")
+    ap.add_argument("--only", default="", help="comma list of knob kinds to walk: g, g4, w, p = only the weight gradients' "
+                    "place in the step (default: all)")
     ap.add_argument("--out", default=os.path.join(ROOT, "hm_vae_amd", "assets", "tune_mi355x.json"))
     a = ap.parse_args()
     import bench
@@ -101,8 +102,12 @@ def main():
     for ps in range(a.passes):
         improved = False
         for kind, obj in knobs:
-            if a.only and kind not in a.only.split(","):
+            only = a.only.split(",") if a.only else []
+            place_only = kind == "w" and "p" in only and "w" not in only      # "p": only the weight gradients' place in the step
+            if only and kind not in only and not place_only:
                 continue
+            if place_only and (getattr(obj, "fwd", None) is None or not hasattr(obj, "t_out")):
+                continue                         # (convolutions only: the engine tags their launches)
             base = measure()                 # the incumbent, re-timed: clocks drift over a run of several minutes
             noise = 0.002 * base
             if kind == "g4":
@@ -178,7 +183,9 @@ def main():
                     ([3] if (ops.WGRAD_BF3 and obj.lds_eligible() and obj.pair_eligible()) else [])
                 splits = [c for c in obj.split_candidates(bp) if not a.fast or c in (1, 2, 3, 4, 6, 8)]
                 cands = [(c, m) for m in modes for c in splits if (c, m) != cur]
-                if ops.WGRAD_BF3 and obj.lds_eligible() and obj.wide() is not None:      # wide tiles: their own short list of splits
+                if place_only:
+                    cands = []
+                if not place_only and ops.WGRAD_BF3 and obj.lds_eligible() and obj.wide() is not None:      # wide tiles: their own short list of splits
                     cands += [(c, 4) for c in obj.wide_split_candidates(bp) if c in obj.split_candidates(bp) and (c, 4) != cur]
                 best_c, best_t = cur, base
                 for c, m in cands:
