@@ -49,6 +49,27 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define STAMP4(i)
 #endif
 
+#include <cstdlib>
+
+// Issue priority of the data path's waves over whatever runs beside them (the weight gradients on their side streams): the
+// launches of the forward / data-gradient chain wait for one another, the side work does not.  HMVAE_CHAIN_PRIO=0..3 (default 3), read once.
+// Measured on the graph step at B = 256, three interleaved rounds: 1.337 (0) -> 1.311 ms (1 or 3).
+static int chain_prio() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("HMVAE_CHAIN_PRIO");
+        v = e ? atoi(e) : 3;
+        if (v < 0 || v > 3) v = 3;
+    }
+    return v;
+}
+#define CHAIN_SETPRIO(p)                                   \
+    do {                                                   \
+        if ((p) == 1) __builtin_amdgcn_s_setprio(1);       \
+        else if ((p) == 2) __builtin_amdgcn_s_setprio(2);  \
+        else if ((p) == 3) __builtin_amdgcn_s_setprio(3);  \
+    } while (0)
+
 namespace {
 
 #ifndef V4_R14
@@ -84,7 +105,8 @@ __device__ __forceinline__ unsigned chunk_swz(unsigned k) {
 // activation images -- were built in round 2, measured never faster than this plain form at 256 and 1 024 sequences per GPU
 // on any layer side, with four- and eight-wave workgroups alike, and removed in round 3: DESIGN.md 4.6 / EXPERIMENTS.md.)
 template <int MTW, int NT, int R>
-__global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d) {
+__global__ __launch_bounds__(256, 2) void gather_gemm4_kernel(hmvae_gemm4_desc d, int prio) {
+    CHAIN_SETPRIO(prio);
     constexpr int NC = NT * 16;                  // columns of the unit
     constexpr int PITCH = NC * 2;                // bytes per image row
     constexpr unsigned PLB = 32 * PITCH;         // bytes per plane
@@ -536,7 +558,7 @@ int launch4(const hmvae_gemm4_desc* d, hipStream_t s) {
     }
     const int n_wg = d->n_units * d->n_split;
     const int per = (n_wg + 7) / 8;
-    hipLaunchKernelGGL((gather_gemm4_kernel<MTW, NT, R>), dim3((unsigned)(per * 8)), dim3(256), lds, s, *d);
+    hipLaunchKernelGGL((gather_gemm4_kernel<MTW, NT, R>), dim3((unsigned)(per * 8)), dim3(256), lds, s, *d, chain_prio());
     return hipGetLastError() == hipSuccess ? HMVAE_OK : HMVAE_ERR_LAUNCH;
 }
 
