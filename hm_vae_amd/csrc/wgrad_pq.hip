@@ -31,6 +31,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte store at any 4-byte boundary
 
 namespace {
 
@@ -53,6 +54,12 @@ __device__ __forceinline__ unsigned swz(unsigned row, unsigned slot) { return (s
 
 __global__ __launch_bounds__(256, 2) void wgrad_pq_kernel(hmvae_wgrad_pq_desc d) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    // the epilogue's look-ups, fetched while the first stage is in flight: mask bytes of the tile's (row, channel) pairs and
+    // the dense ids of every packed id's children (read at the tile's end they were chains of dependent global loads: 12 of
+    // the launch's 42 us with the scalar stores below them)
+    __shared__ unsigned char s_ok[128 * 128 / 16];          // RT * CT <= 1024 pairs
+    __shared__ int s_child[128 * 4];                        // child ids of the tile's channels (child_side 0) or rows (1)
+    __shared__ float s_scale[128];
     char* bufA = lds;
     char* bufB = lds + 3 * PL;
 
@@ -118,6 +125,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_pq_kernel(hmvae_wgrad_pq_desc d)
     };
     const int n_stage = d.bp >> 5;
     fetch(0);
+    {
+        const int lct0 = 7 - ls, CT0 = 1 << lct0, RT0 = TILE >> lt;
+        for (int i = threadIdx.x; i < RT0 * CT0; i += 256) {
+            const int r = r0 + (i >> lct0), c = c0 + (i & (CT0 - 1));
+            s_ok[i] = (r < d.n_rows && c < d.n_chan) ? d.ok[(size_t)r * d.n_chan + c] : (unsigned char)0;
+        }
+        if (d.child_tab != nullptr) {
+            const int n_id = d.child_side ? RT0 : CT0, id0 = d.child_side ? r0 : c0, id_end = d.child_side ? d.n_rows : d.n_chan;
+            for (int i = threadIdx.x; i < n_id * 4; i += 256) s_child[i] = id0 + (i >> 2) < id_end ? d.child_tab[(id0 + (i >> 2)) * 4 + (i & 3)] : -1;
+            for (int i = threadIdx.x; i < n_id; i += 256)
+                s_scale[i] = (d.child_scale && id0 + i < id_end) ? d.child_scale[id0 + i] : 1.f;
+        }
+    }
     for (int s = 0; s < n_stage; ++s) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) put(bufA, st[ps], ra[ps]);
@@ -181,9 +201,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_pq_kernel(hmvae_wgrad_pq_desc d)
         __syncthreads();
         for (int blk = wave; blk < n_blk; blk += 4) {
             const int rc = blk * 16 + n;
-            const int r = r0 + pass * (64 >> lt) + (rc >> lct), c = c0 + (rc & (CT - 1));
-            const bool in = r < d.n_rows && c < d.n_chan;
-            const unsigned bits = in ? d.ok[(size_t)r * d.n_chan + c] : 0u;     // issued before the contraction, used after it
+            const int r_l = pass * (64 >> lt) + (rc >> lct), c_l = rc & (CT - 1);
+            const int r = r0 + r_l, c = c0 + c_l;
+            const unsigned bits = s_ok[(r_l << lct) + c_l];
             f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
             const float* gp = G + kk * GST + rc;
             const float* mp = Mt + kk * 16 + n;
@@ -191,23 +211,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_pq_kernel(hmvae_wgrad_pq_desc d)
             for (int pq = 0; pq < PQ; pq += 4)
                 s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(mp[pq * 16], gp[pq * GST], s4, 0, 0, 0);
             if (!bits) continue;
-            // s4[i] = dW of tap 4 kk + i for the packed (row, channel) pair rc
-            if (d.child_tab == nullptr) {
-                float* o = d.dense + (size_t)r * d.row_stride + (size_t)c * d.chan_stride + 4 * kk;
+            // s4[i] = dW of tap 4 kk + i for the packed (row, channel) pair rc: the four lanes (kk) of a pair write its kt
+            // consecutive floats, 16 bytes each -- neighbouring pairs' runs are adjacent in the dense tensor
+            const int nk = d.kt - 4 * kk;                         // taps this lane holds: >= 4, 3, 2, 1 or <= 0
+            if (nk <= 0) continue;
+            const bool has_tab = d.child_tab != nullptr;
+            const int cid = d.child_side ? r_l : c_l;
+            const float sc = has_tab ? s_scale[cid] : 1.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (4 * kk + i < d.kt) o[i] = d.accumulate ? o[i] + s4[i] : s4[i];
-            } else {
-                const float sc = d.child_scale ? d.child_scale[d.child_side ? r : c] : 1.f;
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci) {
-                    if (!((bits >> ci) & 1u)) continue;
-                    const int dr = d.child_side ? d.child_tab[r * 4 + ci] : r;
-                    const int dc = d.child_side ? c : d.child_tab[c * 4 + ci];
-                    float* o = d.dense + (size_t)dr * d.row_stride + (size_t)dc * d.chan_stride + 4 * kk;
+            for (int ci = 0; ci < 4; ++ci) {
+                if (!((bits >> ci) & 1u)) continue;
+                int dr = r, dc = c;
+                if (has_tab) {
+                    const int ch = s_child[cid * 4 + ci];
+                    if (d.child_side) dr = ch; else dc = ch;
+                } else if (ci > 0) {
+                    break;
+                }
+                float* o = d.dense + (size_t)dr * d.row_stride + (size_t)dc * d.chan_stride + 4 * kk;
+                f32x4 v = s4 * sc;
+                if (d.accumulate) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (4 * kk + i < d.kt) o[i] = d.accumulate ? o[i] + s4[i] * sc : s4[i] * sc;
+                        if (i < nk) v[i] += o[i];
+                }
+                if (nk >= 4) {
+                    *(f32x4u*)o = v;
+                } else {
+                    o[0] = v[0];
+                    if (nk > 1) o[1] = v[1];
+                    if (nk > 2) o[2] = v[2];
                 }
             }
         }
@@ -222,11 +255,11 @@ static size_t pq_lds_bytes(int log_t, int log_s) {
     if (log_t < 0 || log_s < 0 || log_t > 6 || log_s > 7) return 0;        // a half tile holds whole rows: t_dst <= 64
     const size_t PQ = (size_t)1 << (log_t + log_s);
     const size_t RCH = ((size_t)64 >> log_t) * ((size_t)TILE >> log_s);
-    if (RCH < 16) return 0;
+    if (RCH < 16 || PQ < 16) return 0;                       // (the epilogue's mask table holds 16384 / PQ <= 1024 pairs)
     const size_t gst = RCH + (PQ * (RCH + 16 + 16) * sizeof(float) <= 6 * (size_t)PL ? 16 : 1);
     size_t lds = (PQ * gst + PQ * 16) * sizeof(float);
     if (lds < 6 * (size_t)PL) lds = 6 * PL;
-    return lds <= 160 * 1024 ? lds : 0;
+    return lds <= 160 * 1024 - 4096 ? lds : 0;               // (the kernel's static tables sit beside the dynamic block)
 }
 
 extern "C" int hmvae_wgrad_pq(const hmvae_wgrad_pq_desc* d, hmvae_stream_t stream) {
@@ -240,7 +273,7 @@ extern "C" int hmvae_wgrad_pq(const hmvae_wgrad_pq_desc* d, hmvae_stream_t strea
     if (!lds) return HMVAE_ERR_UNSUPPORTED;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)wgrad_pq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)wgrad_pq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess)
             return HMVAE_ERR_LAUNCH;
         attr = true;
     }

@@ -888,11 +888,11 @@ class MaskedGemm:
             return None
         pq = t_dst * t_src
         rch = (64 // t_dst) * (128 // t_src)                 # the epilogue takes the tile's rows in two halves
-        if rch < 16:
+        if rch < 16 or pq < 16:
             return None
         gst = rch + (16 if pq * (rch + 32) * 4 <= 6 * 128 * 64 else 1)
         lds = max((pq * gst + pq * 16) * 4, 6 * 128 * 64)
-        return lds if lds <= 160 * 1024 else None
+        return lds if lds <= 160 * 1024 - 4096 else None
 
     def pq(self):
         """Tables of the position-pair weight gradient (hmvae_wgrad_pq_desc), or None where it does not apply: position
