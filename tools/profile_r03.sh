@@ -10,4 +10,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_traj -- python3 $R/bench.py --only traj --steps 20 --warmup 5 > $R/gpurun_out/prof_${TAG}_traj.log 2>&1 &&
 bash $R/tools/pmc_wgrad3.sh dec0 2 1 &&
 bash $R/tools/pmc_wgrad3.sh dec0 4 1 &&
+bash $R/tools/pmc_wgrad3.sh dec0 pq 1 &&
 echo all profiles done
