@@ -294,7 +294,8 @@ int hmvae_wgrad_gemm(const hmvae_wgrad_desc* desc, hmvae_stream_t stream);
  *   channels starting at (tile_r0, tile_c0); tiles whose mask bytes are all zero need not be listed.
  *   ok[r * n_chan + c]: bit i = child i of the packed id on the child side takes the value (bit 0 alone without child_tab).
  *   m[(p * t_src + q) * 16 + k] = M[p, q, k], zero for k >= kt.
- * HMVAE_ERR_UNSUPPORTED when the epilogue's image (t_dst * t_src * (8192 / (t_dst * t_src) + 17) floats) exceeds the LDS.
+ * HMVAE_ERR_UNSUPPORTED when t_dst * t_src < 16 or the epilogue's image (t_dst * t_src * (8192 / (t_dst * t_src) + 17) floats)
+ * exceeds the LDS.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
     const float* dz;
