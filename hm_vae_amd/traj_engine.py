@@ -226,7 +226,8 @@ class TrajEngine(_StepBase):
             x = w["X0"] if i == 0 else w["A%d" % (i - 1)]
             base = (np.arange(p.enc_cout[i]) * T).astype(np.int32)
             self._wgrad(self.conv[i], w["dY%d" % i], x, enc_w[i], bp, w,
-                        (w["dY%d" % i], enc_b[i], ("convb", i), base, p.enc_cout[i], T, 1))
+                        (w["dY%d" % i], enc_b[i], ("convb", i), base, p.enc_cout[i], T, 1), tag="enc%d" % i)
             if i > 0:
                 self.conv[i].backward_data(w["dY%d" % i], w["dA%d" % (i - 1)], bp)
+            self._flush_delayed()               # weight gradients placed behind this data-gradient launch (ops.MaskedGemm.wg_delay)
         self._join()
