@@ -362,6 +362,30 @@ def test_graph_replay_split_path_matches_single_graph(dev, monkeypatch):
         assert frac_close > 0.9999, (k, frac_close)
 
 
+def test_placed_weight_gradients_change_nothing(dev, monkeypatch):
+    """engine._wgrad queues a layer's weight gradient n data-gradient launches after its own (ops.MaskedGemm.wg_delay / HMVAE_WG_DELAY;
+    pending launches are flushed where a segment ends): WHEN a gradient is computed changes neither its operands nor its kernel, so
+    three graph steps with every convolution's launch moved -- position-pair launches included -- end on the same parameters to the bit."""
+    from hm_vae_amd import engine as E, ops
+    from hm_vae_amd.graph_step import GraphedStep
+    g, meta = load_model_golden("len64")
+    batch = golden_batch(g)
+    monkeypatch.setattr(ops, "WGRAD_PQ", "1")
+    outs = []
+    for delays in ({}, {"dec3": 1, "dec2": 2, "dec1": 2, "dec0": 3, "enc3": 2, "enc2": 1, "enc1": 9}):
+        monkeypatch.setattr(E, "WG_DELAY", delays)
+        cfg, plan, tr, seeded = make_trainer("len64", dev)
+        torch.manual_seed(77)
+        step = GraphedStep(tr, cfg, batch, cfg["iteration_interval"], use_graph=True, warmup=1)
+        losses = [step.run() for _ in range(3)]
+        eng = tr.model.engine()
+        bp = eng.workspace(batch[0].shape[0])["bp"]
+        assert sum(c.use_pq(bp) for c in eng.enc_conv + eng.dec_conv) >= 3
+        outs.append((np.array(losses), torch.cat([p.detach().reshape(-1) for p in tr.model.parameters() if p.requires_grad]).cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_ingraph_allreduce_world_of_one(dev, monkeypatch):
     """HMVAE_DDP_INGRAPH=1: the whole DDP step, slice all-reduces included, captured in ONE hipGraph (RCCL collectives
     issued from a helper stream behind exactly the launches that write each slice).  On a one-GPU box the process group
