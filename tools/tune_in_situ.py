@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--no-v4", action="store_true", help="leave the v4 (bf16-plane) gather choices as the autotuner made them")
     ap.add_argument("--only", default="", help="comma list of knob kinds to walk: g, g4, w, p = only the weight gradients' "
                     "place in the step (default: all)")
+    ap.add_argument("--match", default="", help="walk only the knobs whose tune key contains this")
     ap.add_argument("--out", default=os.path.join(ROOT, "hm_vae_amd", "assets", "tune_mi355x.json"))
     a = ap.parse_args()
     import bench
@@ -103,6 +104,8 @@ def main():
         improved = False
         for kind, obj in knobs:
             only = a.only.split(",") if a.only else []
+            if a.match and a.match not in (obj.wg_tune_key(bp) if kind == "w" else obj.tune_key(bp)):
+                continue
             place_only = kind == "w" and "p" in only and "w" not in only      # "p": only the weight gradients' place in the step
             if only and kind not in only and not place_only:
                 continue
